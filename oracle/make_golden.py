@@ -1,0 +1,172 @@
+"""TEST INFRASTRUCTURE ONLY -- writes tests/golden/*.npz from the real reference.
+
+Run in the build container only (needs /root/reference, which never travels to the
+GPU box):
+
+    PYTHONDONTWRITEBYTECODE=1 python oracle/make_golden.py
+
+It imports the reference package read-only, runs every hot-path layer
+with ``np.random.seed`` fixed, and stores inputs, initial params, outputs, input
+grads and post-SGD params.  The fixtures are DATA (arrays), not source.  Each file
+records ``numpy_version`` because the reference's dtypes depend on it (NEP 50).
+"""
+
+import io
+import os
+import sys
+import contextlib
+
+import numpy as np
+
+REFERENCE = os.environ.get('NPM_REFERENCE', '/root/reference')
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests', 'golden')
+
+
+def _ref():
+    sys.dont_write_bytecode = True
+    sys.path.insert(0, REFERENCE)
+    import layers, optimizer, loss, train  # noqa: E401
+    return layers, optimizer, loss, train
+
+
+def rand(shape):
+    return np.random.normal(size=shape).astype(np.float32)
+
+
+def save(name, **arrays):
+    arrays['numpy_version'] = np.array(np.__version__)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'{name}: {os.path.getsize(path) / 1024:.0f} KiB')
+
+
+def gen_dense(layers, with_relu, name):
+    np.random.seed(0)
+    layer = layers.Dense(units=16) if with_relu else layers.Linear(units=16)
+    x = rand([64, 32])
+    y = layer(x)
+    lin = layer.linear if with_relu else layer
+    w0, b0 = lin.w.copy(), lin.b.copy()
+    dy = rand([64, 16])
+    dx = layer(dy, backprop=True, learning_rate=0.01)
+    save(name, x=x, w0=w0, b0=b0, y=y, dy=dy, dx=dx, w1=lin.w, b1=lin.b, lr=np.float64(0.01))
+
+
+def gen_activations(layers):
+    np.random.seed(0)
+    x = rand([48, 40])
+    dy = rand([48, 40])
+    relu = layers.ReLU()
+    x[0, :5] = 0.0                      # exercise the x == 0 branch of the >= test
+    y = relu(x)
+    dx = relu.backward(dy)
+    save('relu', x=x, y=y, dy=dy, dx=dx)
+    np.random.seed(1)
+    sm = layers.Softmax()
+    x = rand([6, 24, 40]) * 3.0
+    dy = rand([6, 24, 40])
+    y = sm(x)
+    dx = sm(dy, backprop=True)
+    save('softmax', x=x, y=y, dy=dy, dx=dx)
+
+
+def gen_layernorm(layers, shape, eps, name):
+    np.random.seed(0)
+    ln = layers.LayerNormalization() if eps is None else layers.LayerNormalization(epsilon=eps)
+    x = rand(shape) * 2.0 + 0.5
+    z = ln(x)
+    g0, b0 = ln._gamma.copy(), ln._beta.copy()
+    dz = rand(shape)
+    dx = ln(dz, backprop=True, learning_rate=1e-3)
+    save(name, x=x, gamma0=g0, beta0=b0, eps=np.float64(ln._epsilon), z=z, dz=dz, dx=dx,
+         gamma1=ln._gamma, beta1=ln._beta, lr=np.float64(1e-3))
+
+
+def gen_conv(layers, shape, channels, k, name):
+    np.random.seed(0)
+    layer = layers.Conv2D(channels=channels, kernel_size=k)
+    x = rand(shape)
+    y = layer(x)
+    w0, b0 = layer.w.copy(), layer.b.copy()
+    dy = rand(y.shape)
+    dx = layer(dy, backprop=True, learning_rate=0.01)
+    save(name, x=x, w0=w0, b0=b0, y=y, dy=dy, dx=dx, w1=layer.w, b1=layer.b, lr=np.float64(0.01))
+
+
+def gen_mha(layers, batch, sq, skv, feat, heads, name):
+    np.random.seed(0)
+    layer = layers.MultiHeadAttention(num_heads=heads)
+    query = rand([batch, sq, feat])
+    cross = skv is not None
+    kv = rand([batch, skv, feat]) if cross else None
+    out = layer(query, kv) if cross else layer(query)
+    names = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+    p0 = {f'{n}0': getattr(layer, '_' + n).copy() for n in names}
+    dy = rand(out.shape) * 0.05
+    dq, dk, dv = layer(dy, backprop=True, learning_rate=0.01)
+    p1 = {f'{n}1': getattr(layer, '_' + n) for n in names}
+    extra = dict(kv=kv) if cross else {}
+    save(name, query=query, out=out, dy=dy, dquery=dq, dkey=dk, dvalue=dv,
+         heads=np.int64(heads), lr=np.float64(0.01), **p0, **p1, **extra)
+
+
+def gen_encoder(layers, norm_first, name):
+    np.random.seed(0)
+    enc = layers.TransformerEncoder(num_heads=4, hidden_units=96, norm_first=norm_first)
+    qkv = rand([3, 16, 48])
+    out = enc(qkv)
+    att = enc._self_attention
+    subs = {'att_' + n: (att, '_' + n) for n in ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']}
+    subs.update(n1_gamma=(enc._norm1, '_gamma'), n1_beta=(enc._norm1, '_beta'),
+                n2_gamma=(enc._norm2, '_gamma'), n2_beta=(enc._norm2, '_beta'),
+                d1_w=(enc._dense1._linear, '_w'), d1_b=(enc._dense1._linear, '_b'),
+                d2_w=(enc._dense2, '_w'), d2_b=(enc._dense2, '_b'))
+    p0 = {k + '__0': getattr(o, a).copy() for k, (o, a) in subs.items()}
+    dy = rand(out.shape) * 0.05
+    dx = enc(dy, backprop=True, learning_rate=1e-3)
+    p1 = {k + '__1': getattr(o, a) for k, (o, a) in subs.items()}
+    save(name, qkv=qkv, out=out, dy=dy, dx=dx, norm_first=np.bool_(norm_first),
+         heads=np.int64(4), hidden=np.int64(96), lr=np.float64(1e-3), **p0, **p1)
+
+
+def gen_train(layers, optimizer, train):
+    """train_test.py:14-49 flow; the printed losses are the known answers."""
+    import re
+    for opt_name in ('sgd', 'adam'):
+        np.random.seed(0)
+        feats = [16, 32, 64, 32, 16]
+        stack = [layers.Dense(units=f, name=f'layer_{i}') for i, f in enumerate(feats)]
+        x = np.random.uniform(0.0, 1.0, size=[128, 16]).astype(np.float32)
+        t = np.random.uniform(0.0, 1.0, size=[128, 16]).astype(np.float32)
+        opt = optimizer.AdamOptimizer(1e-4) if opt_name == 'adam' else optimizer.SGDOptimizer(1e-4)
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            tr = train.Trainer(stack)
+            tr.train(inputs=x, targets=t, steps=10, optimizer_=opt)
+            tr.eval(inputs=x, targets=t)
+        losses = np.array([float(v) for v in re.findall(r'Loss:\s+([0-9.eE+-]+)', buf.getvalue())])
+        assert losses.size == 11
+        final = {f'w{i}': l.linear.w for i, l in enumerate(stack)}
+        save('train_mlp_' + opt_name, x=x, targets=t, losses=losses, lr=np.float64(1e-4), **final)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    layers, optimizer, loss, train = _ref()
+    gen_dense(layers, True, 'dense')
+    gen_dense(layers, False, 'linear')
+    gen_activations(layers)
+    gen_layernorm(layers, [32, 128], 1e-6, 'layernorm_2d')
+    gen_layernorm(layers, [3, 10, 72], None, 'layernorm_3d')
+    gen_conv(layers, [3, 9, 7, 8], 12, 3, 'conv_k3')
+    gen_conv(layers, [2, 8, 8, 4], 6, 5, 'conv_k5')
+    gen_conv(layers, [2, 6, 5, 8], 4, 1, 'conv_k1')
+    gen_mha(layers, 4, 24, None, 64, 8, 'mha_self')
+    gen_mha(layers, 3, 10, 28, 48, 4, 'mha_cross')
+    gen_encoder(layers, True, 'encoder_prenorm')
+    gen_encoder(layers, False, 'encoder_postnorm')
+    gen_train(layers, optimizer, train)
+
+
+if __name__ == '__main__':
+    main()

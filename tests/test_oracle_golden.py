@@ -1,0 +1,165 @@
+"""CPU: the oracle (both flavours) against fixtures produced by the real reference.
+
+Fixtures come from oracle/make_golden.py (imports /root/reference in the build
+container).  Tolerances: the oracle repeats the reference's NumPy expressions, so
+results agree to rounding; closed forms differ from the Jacobian forms by a few ulp
+of fp32-scaled values (SURVEY.md 8c measured 1.3e-8 / 3.5e-7)."""
+
+import numpy as np
+import pytest
+
+from oracle import np_oracle as O
+from conftest import load_golden
+
+TIGHT = dict(rtol=1e-6, atol=1e-6)
+
+
+def close(a, b, **kw):
+    tol = dict(TIGHT)
+    tol.update(kw)
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), **tol)
+
+
+def close_scaled(a, b, tol=1e-5):
+    """|a-b| <= tol * (|b| + max|b|): the GEMM-reordering flavour differs from the
+    reference's einsum order by fp32 rounding of O(max|b|) * eps per element."""
+    b = np.asarray(b, dtype=np.float64)
+    np.testing.assert_allclose(np.asarray(a, dtype=np.float64), b, rtol=tol, atol=tol * np.abs(b).max())
+
+
+@pytest.mark.parametrize('name,relu', [('dense', True), ('linear', False)])
+def test_dense(name, relu):
+    g = load_golden(name)
+    if relu:
+        y, pre = O.dense_fwd(g['x'], g['w0'], g['b0'])
+        dx, dw, db = O.dense_bwd(g['x'], g['w0'], pre, g['dy'])
+    else:
+        y = O.linear_fwd(g['x'], g['w0'], g['b0'])
+        dx, dw, db = O.linear_bwd(g['x'], g['w0'], g['dy'])
+    close(y, g['y'])
+    close(dx, g['dx'])
+    close(O.sgd_step(g['w0'], dw, float(g['lr'])), g['w1'])
+    close(O.sgd_step(g['b0'], db, float(g['lr'])), g['b1'])
+
+
+def test_relu_passes_gradient_at_zero():
+    g = load_golden('relu')
+    close(O.relu_fwd(g['x']), g['y'])
+    dx = O.relu_bwd(g['x'], g['dy'])
+    close(dx, g['dx'])
+    assert np.all(dx[0, :5] == g['dy'][0, :5])      # x == 0 -> gradient passes (>=)
+
+
+@pytest.mark.parametrize('verbatim', [True, False])
+def test_softmax(verbatim):
+    g = load_golden('softmax')
+    y = O.softmax_fwd(g['x'])
+    close(y, g['y'])
+    close(O.softmax_bwd(y, g['dy'], verbatim=verbatim), g['dx'], atol=1e-7)
+
+
+@pytest.mark.parametrize('name', ['layernorm_2d', 'layernorm_3d'])
+@pytest.mark.parametrize('verbatim', [True, False])
+def test_layernorm(name, verbatim):
+    g = load_golden(name)
+    eps = float(g['eps'])
+    z, cache = O.layernorm_fwd(g['x'], g['gamma0'], g['beta0'], eps)
+    close(z, g['z'])
+    dx, dgamma, dbeta = O.layernorm_bwd(g['x'], g['gamma0'], eps, cache, g['dz'], verbatim=verbatim)
+    close(dx, g['dx'], atol=5e-6)
+    close(O.sgd_step(g['gamma0'], dgamma, float(g['lr'])), g['gamma1'])
+    close(O.sgd_step(g['beta0'], dbeta, float(g['lr'])), g['beta1'])
+
+
+@pytest.mark.parametrize('name', ['conv_k1', 'conv_k3', 'conv_k5'])
+def test_conv(name):
+    g = load_golden(name)
+    y, pre = O.conv_layer_fwd(g['x'], g['w0'], g['b0'])
+    close(y, g['y'])
+    dx, dw, db = O.conv_layer_bwd(g['x'], g['w0'], pre, g['dy'])
+    close(dx, g['dx'])
+    close(O.sgd_step(g['w0'], dw, float(g['lr'])), g['w1'])
+    close(O.sgd_step(g['b0'], db, float(g['lr'])), g['b1'])
+
+
+@pytest.mark.parametrize('name', ['mha_self', 'mha_cross'])
+@pytest.mark.parametrize('verbatim', [True, False])
+def test_mha(name, verbatim):
+    g = load_golden(name)
+    p = {n: g[n + '0'] for n in O.MHA_PARAM_NAMES}
+    kv = g.get('kv')
+    out, cache = O.mha_fwd(p, g['query'], kv, verbatim=verbatim)
+    close_scaled(out, g['out'])
+    (dq, dk, dv), grads = O.mha_bwd(p, cache, g['dy'], verbatim=verbatim)
+    close_scaled(dq, g['dquery'])
+    close_scaled(dk, g['dkey'])
+    close_scaled(dv, g['dvalue'])
+    for n in O.MHA_PARAM_NAMES:
+        close_scaled(O.sgd_step(p[n], grads[n], float(g['lr'])), g[n + '1'])
+
+
+@pytest.mark.parametrize('name', ['encoder_prenorm', 'encoder_postnorm'])
+@pytest.mark.parametrize('verbatim', [True, False])
+def test_encoder(name, verbatim):
+    g = load_golden(name)
+    nf = bool(g['norm_first'])
+    p = {k[:-3]: v for k, v in g.items() if k.endswith('__0')}
+    out, cache = O.encoder_fwd(p, g['qkv'], nf, verbatim=verbatim)
+    close_scaled(out, g['out'])
+    dx, grads = O.encoder_bwd(p, cache, g['dy'], nf, verbatim=verbatim)
+    close_scaled(dx, g['dx'])
+    for k, grad in grads.items():
+        close_scaled(O.sgd_step(p[k], grad, float(g['lr'])), g[k + '__1'])
+
+
+@pytest.mark.parametrize('norm_first', [True, False])
+def test_encoder_init_draw_order(norm_first):
+    """Seeded param draws reproduce the reference's lazy-initialisation order."""
+    g = load_golden('encoder_prenorm' if norm_first else 'encoder_postnorm')
+    # make_golden draws qkv first (rand) and the params lazily at the first call:
+    np.random.seed(0)
+    qkv = np.random.normal(size=g['qkv'].shape).astype(np.float32)
+    p = O.encoder_init_ordered(int(g['heads']), int(g['hidden']), qkv.shape[-1], norm_first)
+    np.testing.assert_array_equal(qkv, g['qkv'])
+    for k, v in p.items():
+        np.testing.assert_array_equal(v, g[k + '__0'], err_msg=k)
+
+
+@pytest.mark.parametrize('opt', ['sgd', 'adam'])
+def test_train_mlp_trajectory(opt):
+    """train_test.py MLP flow: 10 steps + eval; losses are the reference's printed values."""
+    g = load_golden('train_mlp_' + opt)
+    np.random.seed(0)
+    feats = [16, 32, 64, 32, 16]
+    x = np.random.uniform(0.0, 1.0, size=[128, 16]).astype(np.float32)
+    t = np.random.uniform(0.0, 1.0, size=[128, 16]).astype(np.float32)
+    np.testing.assert_array_equal(x, g['x'])
+    params, states = [], []
+    losses = []
+    lr = float(g['lr'])
+    for step in range(11):
+        acts, pres = [x], []
+        for i, f in enumerate(feats):
+            if step == 0:
+                w = O.random_init([acts[-1].shape[-1], f])
+                b = O.random_init([f])
+                params.append([w, b])
+                states.append([{}, {}])
+            y, pre = O.dense_fwd(acts[-1], *params[i])
+            acts.append(y)
+            pres.append(pre)
+        losses.append(O.mse_fwd(acts[-1], t))
+        if step == 10:
+            break
+        dy = O.mse_bwd(acts[-1], t)
+        for i in reversed(range(len(feats))):
+            dy, dw, db = O.dense_bwd(acts[i], params[i][0], pres[i], dy)
+            if opt == 'sgd':
+                params[i][0] = O.sgd_step(params[i][0], dw, lr)
+                params[i][1] = O.sgd_step(params[i][1], db, lr)
+            else:
+                params[i][0] = O.adam_step(params[i][0], dw, states[i][0], lr)
+                params[i][1] = O.adam_step(params[i][1], db, states[i][1], lr)
+    np.testing.assert_allclose(losses, g['losses'], rtol=2e-5)
+    for i in range(len(feats)):
+        close(params[i][0], g[f'w{i}'], rtol=1e-5, atol=1e-5)
