@@ -1,0 +1,48 @@
+/*
+ * npm_comm.h -- C ABI of the data-parallel gradient exchange (RCCL over xGMI).
+ *
+ * The reference (levendlee/np-modeling) is single-process: it has no communication
+ * code to mirror.  This is the one exchange step of the batch-sharded hot path
+ * (SURVEY.md section 8e): an all-reduce of the parameter gradients between
+ * Layer.backward's gradient computation and optimizer_.update (reference call sites
+ * layers/mlp.py:38-39, layers/normalizations.py:73-74, layers/attentions.py:190-197).
+ *
+ * One process per GPU.  Rank 0 creates the id, the launcher's store carries it to the
+ * other ranks (host side: np_modeling_amd/parallel.py), every rank calls npm_comm_init.
+ * Collectives run on a dedicated communication stream so they overlap the rest of the
+ * backward pass; ordering against the compute stream is by HIP events.
+ */
+#ifndef NPM_COMM_H
+#define NPM_COMM_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPM_COMM_ID_BYTES 128
+
+enum { NPM_REDUCE_SUM = 0, NPM_REDUCE_AVG = 1, NPM_REDUCE_MAX = 2 };
+
+const char *npm_comm_last_error(void);
+int npm_comm_unique_id(char *id /* NPM_COMM_ID_BYTES */);
+/* compute_stream: npm_stream() of libnpm_hip.so (the stream gradients are produced on) */
+int npm_comm_init(const char *id, int rank, int nranks, void *compute_stream);
+int npm_comm_rank(int *rank, int *nranks);
+/* In-place all-reduce of buf[0..count); issued on the comm stream after everything already
+ * queued on the compute stream.  Returns immediately (asynchronous). */
+int npm_comm_allreduce_f32(float *buf, size_t count, int op);
+int npm_comm_broadcast_f32(float *buf, size_t count, int root);
+/* Make the compute stream wait for every collective issued so far. */
+int npm_comm_wait(void);
+/* Host-blocking: all ranks have reached this point and their GPU work is complete. */
+int npm_comm_barrier(void);
+/* Host scalar reduction (bench.py: max over ranks of the elapsed time). */
+int npm_comm_allreduce_host_f64(double *value, int op);
+int npm_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPM_COMM_H */

@@ -1,0 +1,144 @@
+/*
+ * npm_hip.h -- C ABI of the MI355X (gfx950) layer forward/backward hot path.
+ *
+ * This is the drop-in boundary.  The reference
+ * (levendlee/np-modeling) is pure NumPy: it has no FFI, so every entry point below
+ * replaces a NumPy call site instead of a native symbol; the site is cited as
+ * reference file:line.  A maintainer binds these with ctypes.
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; every function returns 0 on success or a
+ *     non-zero hipError_t / NPM_E_* code, and npm_last_error() describes the failure.
+ *   - One process drives one GPU: npm_init(device) binds the process to a device and
+ *     creates the compute stream all launches go to.  Launches are asynchronous;
+ *     npm_sync() / npm_d2h() are the synchronisation points.
+ *   - All tensors are fp32, row-major; "ld" is the row pitch in elements.
+ *   - Device pointers come from npm_malloc (a stream-ordered caching pool).
+ */
+#ifndef NPM_HIP_H
+#define NPM_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NPM_ABI_VERSION 1
+
+enum {
+    NPM_OK = 0,
+    NPM_E_NOT_INITIALIZED = 10001,
+    NPM_E_BAD_ARGUMENT = 10002,
+    NPM_E_UNSUPPORTED = 10003,
+    NPM_E_NO_DEVICE = 10004
+};
+
+/* ---- runtime ------------------------------------------------------------ */
+int npm_abi_version(void);
+const char *npm_last_error(void);
+int npm_device_count(int *count);
+int npm_init(int device);                 /* idempotent for the same device */
+int npm_shutdown(void);
+int npm_device_name(char *buf, int len);
+void *npm_stream(void);                   /* the hipStream_t launches go to */
+int npm_sync(void);                       /* hipStreamSynchronize(compute stream) */
+
+/* ---- memory: caching pool over hipMalloc --------------------------------- */
+int npm_malloc(void **ptr, size_t bytes);
+int npm_free(void *ptr);                  /* returns the block to the pool (stream-ordered reuse) */
+int npm_pool_stats(size_t *bytes_in_use, size_t *bytes_reserved);
+int npm_pool_trim(void);                  /* hipFree every cached block */
+int npm_h2d(void *dst, const void *src, size_t bytes);   /* ordered after prior launches; returns when done */
+int npm_d2h(void *dst, const void *src, size_t bytes);   /* ditto */
+int npm_d2d(void *dst, const void *src, size_t bytes);   /* async on the compute stream */
+int npm_fill_f32(float *dst, float value, size_t n);
+
+/* ---- events (HIP events on the compute stream; used by bench.py) ---------- */
+int npm_event_create(void **event);
+int npm_event_destroy(void *event);
+int npm_event_record(void *event);
+int npm_event_sync(void *event);
+int npm_event_elapsed_ms(void *start, void *stop, float *ms);
+
+/* ---- GEMM: C = epilogue(alpha * op(A) op(B)) ------------------------------
+ * Replaces np.matmul in layers/mlp.py:23,35,36 and every np.einsum contraction in
+ * layers/attentions.py:88-117,129-188 (each is a flat or batched GEMM view).
+ * fp32 operands on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.
+ *
+ *   trans_a == 0 : A is [M,K] (pitch lda)      trans_a == 1 : A is stored [K,M]
+ *   trans_b == 0 : B is [K,N] (pitch ldb)      trans_b == 1 : B is stored [N,K]
+ * Batches are indexed z = z0 * batch1 + z1 with operand offset z0*stride0 + z1*stride1
+ * (lets [B,S,H,D] head slices be addressed without a transpose).
+ */
+enum {
+    NPM_EPI_BIAS = 1,        /* + bias[n]                                  (mlp.py:24) */
+    NPM_EPI_RESIDUAL = 2,    /* + residual[m,n] (may alias C: accumulate)  (transformer.py:39,53) */
+    NPM_EPI_RELU_SAVE = 4,   /* aux[m,n] = v; C = max(v,0)                 (activations.py:14-15) */
+    NPM_EPI_RELU_MASK = 8    /* C = aux[m,n] >= 0 ? v : 0                  (activations.py:19) */
+};
+
+typedef struct npm_gemm {
+    int32_t trans_a, trans_b;
+    int32_t m, n, k;
+    int32_t batch0, batch1;              /* >= 1 each */
+    const float *a; int64_t lda, stride_a0, stride_a1;
+    const float *b; int64_t ldb, stride_b0, stride_b1;
+    float *c;       int64_t ldc, stride_c0, stride_c1;
+    float alpha;
+    int32_t epilogue;                    /* NPM_EPI_* bit set */
+    const float *bias;                   /* [n] */
+    const float *residual; int64_t ldr;  /* same batch strides as C */
+    float *aux; int64_t ldaux;           /* same batch strides as C */
+    int32_t split_k;                     /* 0 = choose automatically, 1 = never split */
+} npm_gemm;
+
+int npm_sgemm(const npm_gemm *g);
+
+/* ---- elementwise ---------------------------------------------------------- */
+int npm_relu_fwd(const float *x, float *y, size_t n);                      /* activations.py:15 */
+int npm_relu_bwd(const float *x_pre, const float *dy, float *dx, size_t n);/* activations.py:19 (x >= 0) */
+int npm_add(const float *a, const float *b, float *out, size_t n);          /* transformer.py:39,53,78,90 */
+int npm_add3(const float *a, const float *b, const float *c, float *out, size_t n); /* transformer.py:85 */
+int npm_axpy(float *y, const float *x, float alpha, size_t n);              /* y += alpha*x; optimizer.py:32 */
+int npm_scale(const float *x, float *y, float alpha, size_t n);
+int npm_colsum(const float *x, float *out, int64_t rows, int64_t cols, int64_t ld); /* mlp.py:34 */
+
+/* ---- row kernels (one wavefront per row) ---------------------------------- */
+/* y = softmax(scale * x) over the last axis                    (activations.py:26-29, attentions.py:104) */
+int npm_softmax_fwd(const float *x, float *y, int64_t rows, int64_t n, float scale);
+/* dx = scale * y * (dy - sum(dy*y)): closed form of the Jacobian einsum (activations.py:32-45, attentions.py:155) */
+int npm_softmax_bwd(const float *y, const float *dy, float *dx, int64_t rows, int64_t n, float scale);
+/* z = gamma*(x-mean)*rstd + beta; saves mean and rstd = 1/sqrt(var+eps), biased var (normalizations.py:45-48) */
+int npm_layernorm_fwd(const float *x, const float *gamma, const float *beta, float eps,
+                      int64_t rows, int64_t d, float *z, float *mean, float *rstd);
+/* dx = rstd*(g - mean(g) - yhat*mean(g*yhat)) [+ residual], g = dz*gamma;
+ * dgamma = sum dz*yhat, dbeta = sum dz (normalizations.py:50-75) */
+int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const float *rstd,
+                      const float *gamma, const float *residual, int64_t rows, int64_t d,
+                      float *dx, float *dgamma, float *dbeta);
+
+/* ---- Conv2D: NHWC x HWIO, SAME, stride 1, odd k (layers/conv.py:74-194) ----
+ * Implicit-im2col GEMM on the fp32 MFMA; the im2col matrix is never materialised. */
+typedef struct npm_conv2d {
+    int32_t n, h, w, c_in, c_out, ksize;
+    const float *x;        /* [n,h,w,c_in] */
+    const float *filt;     /* [k,k,c_in,c_out] */
+    const float *bias;     /* [c_out] or NULL */
+    float *y;              /* [n,h,w,c_out] */
+    float *pre;            /* optional pre-activation output when relu != 0 */
+    int32_t relu;
+} npm_conv2d;
+int npm_conv2d_fwd(const npm_conv2d *c);                                           /* conv.py:44-48,97-105 */
+/* dx = conv(dy, flip+transpose(filt))  (conv.py:130,153); mask_pre != NULL applies relu' to dy first */
+int npm_conv2d_bwd_x(const float *dy, const float *filt, float *dx,
+                     int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
+/* dw[i,j] = shifted(x)^T dy  (conv.py:185-194) */
+int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
+                     int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NPM_HIP_H */

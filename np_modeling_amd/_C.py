@@ -1,0 +1,179 @@
+"""ctypes binding of ``libnpm_hip.so`` (C ABI in ``include/npm_hip.h``).
+
+There is no CPU path: if the shared library is missing, or no MI355X is visible, the
+first use raises.  (``import np_modeling_amd`` itself stays importable so that the
+build check can import the package on a machine without a GPU.)
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_DIR = os.path.join(_HERE, 'lib')
+LIB_PATH = os.path.join(LIB_DIR, 'libnpm_hip.so')
+RCCL_LIB_PATH = os.path.join(LIB_DIR, 'libnpm_rccl.so')
+
+
+class NpmError(RuntimeError):
+    """A C-ABI call returned non-zero."""
+
+
+class npm_gemm(C.Structure):
+    _fields_ = [
+        ('trans_a', C.c_int32), ('trans_b', C.c_int32),
+        ('m', C.c_int32), ('n', C.c_int32), ('k', C.c_int32),
+        ('batch0', C.c_int32), ('batch1', C.c_int32),
+        ('a', C.c_void_p), ('lda', C.c_int64), ('stride_a0', C.c_int64), ('stride_a1', C.c_int64),
+        ('b', C.c_void_p), ('ldb', C.c_int64), ('stride_b0', C.c_int64), ('stride_b1', C.c_int64),
+        ('c', C.c_void_p), ('ldc', C.c_int64), ('stride_c0', C.c_int64), ('stride_c1', C.c_int64),
+        ('alpha', C.c_float),
+        ('epilogue', C.c_int32),
+        ('bias', C.c_void_p),
+        ('residual', C.c_void_p), ('ldr', C.c_int64),
+        ('aux', C.c_void_p), ('ldaux', C.c_int64),
+        ('split_k', C.c_int32),
+    ]
+
+
+class npm_conv2d(C.Structure):
+    _fields_ = [
+        ('n', C.c_int32), ('h', C.c_int32), ('w', C.c_int32),
+        ('c_in', C.c_int32), ('c_out', C.c_int32), ('ksize', C.c_int32),
+        ('x', C.c_void_p), ('filt', C.c_void_p), ('bias', C.c_void_p),
+        ('y', C.c_void_p), ('pre', C.c_void_p),
+        ('relu', C.c_int32),
+    ]
+
+
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK = 1, 2, 4, 8
+
+_P, _SZ, _I64, _I32, _F = C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_float
+
+# name -> argtypes; every function returns int (0 = ok) unless listed in _SPECIAL.
+SIGNATURES = {
+    'npm_device_count': [C.POINTER(C.c_int)],
+    'npm_init': [C.c_int],
+    'npm_shutdown': [],
+    'npm_device_name': [C.c_char_p, C.c_int],
+    'npm_sync': [],
+    'npm_malloc': [C.POINTER(_P), _SZ],
+    'npm_free': [_P],
+    'npm_pool_stats': [C.POINTER(_SZ), C.POINTER(_SZ)],
+    'npm_pool_trim': [],
+    'npm_h2d': [_P, _P, _SZ],
+    'npm_d2h': [_P, _P, _SZ],
+    'npm_d2d': [_P, _P, _SZ],
+    'npm_fill_f32': [_P, _F, _SZ],
+    'npm_event_create': [C.POINTER(_P)],
+    'npm_event_destroy': [_P],
+    'npm_event_record': [_P],
+    'npm_event_sync': [_P],
+    'npm_event_elapsed_ms': [_P, _P, C.POINTER(_F)],
+    'npm_sgemm': [C.POINTER(npm_gemm)],
+    'npm_relu_fwd': [_P, _P, _SZ],
+    'npm_relu_bwd': [_P, _P, _P, _SZ],
+    'npm_add': [_P, _P, _P, _SZ],
+    'npm_add3': [_P, _P, _P, _P, _SZ],
+    'npm_axpy': [_P, _P, _F, _SZ],
+    'npm_scale': [_P, _P, _F, _SZ],
+    'npm_colsum': [_P, _P, _I64, _I64, _I64],
+    'npm_softmax_fwd': [_P, _P, _I64, _I64, _F],
+    'npm_softmax_bwd': [_P, _P, _P, _I64, _I64, _F],
+    'npm_layernorm_fwd': [_P, _P, _P, _F, _I64, _I64, _P, _P, _P],
+    'npm_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P],
+    'npm_conv2d_fwd': [C.POINTER(npm_conv2d)],
+    'npm_conv2d_bwd_x': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
+    'npm_conv2d_bwd_w': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
+}
+_SPECIAL = {
+    'npm_abi_version': (C.c_int, []),
+    'npm_last_error': (C.c_char_p, []),
+    'npm_stream': (C.c_void_p, []),
+}
+
+COMM_SIGNATURES = {
+    'npm_comm_unique_id': [C.c_char_p],
+    'npm_comm_init': [C.c_char_p, C.c_int, C.c_int, _P],
+    'npm_comm_rank': [C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    'npm_comm_allreduce_f32': [_P, _SZ, C.c_int],
+    'npm_comm_broadcast_f32': [_P, _SZ, C.c_int],
+    'npm_comm_wait': [],
+    'npm_comm_barrier': [],
+    'npm_comm_allreduce_host_f64': [C.POINTER(C.c_double), C.c_int],
+    'npm_comm_destroy': [],
+}
+_COMM_SPECIAL = {'npm_comm_last_error': (C.c_char_p, [])}
+
+_LIB: Optional[object] = None       # the loaded library (tests may install a host simulator here)
+_COMM_LIB: Optional[object] = None
+_DEVICE: Optional[int] = None
+
+
+def _bind(cdll, signatures, special):
+    for name, argtypes in signatures.items():
+        fn = getattr(cdll, name)
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    for name, (restype, argtypes) in special.items():
+        fn = getattr(cdll, name)
+        fn.argtypes = argtypes
+        fn.restype = restype
+    return cdll
+
+
+def load_library(path: str = LIB_PATH):
+    """dlopen libnpm_hip.so and declare every prototype of include/npm_hip.h."""
+    if not os.path.exists(path):
+        raise NpmError(
+            f'{path} is missing: build the HIP library first '
+            f'(python -c "import __graft_entry__ as g; g.build()" or make -C np_modeling_amd/csrc). '
+            'np_modeling_amd has no CPU fallback.')
+    return _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), SIGNATURES, _SPECIAL)
+
+
+def load_comm_library(path: str = RCCL_LIB_PATH):
+    if not os.path.exists(path):
+        raise NpmError(f'{path} is missing: build it with make -C np_modeling_amd/csrc')
+    return _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), COMM_SIGNATURES, _COMM_SPECIAL)
+
+
+def lib():
+    """The bound, device-initialised library.  Raises if there is no library or no GPU."""
+    global _LIB, _DEVICE
+    if _LIB is None:
+        _LIB = load_library()
+    if _DEVICE is None:
+        device = int(os.environ.get('NPM_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        rc = _LIB.npm_init(device)
+        if rc != 0:
+            msg = _LIB.npm_last_error()
+            raise NpmError(f'npm_init({device}) failed with code {rc}: '
+                           f'{msg.decode() if msg else "?"} -- an MI355X is required, there is no CPU fallback')
+        _DEVICE = device
+    return _LIB
+
+
+def comm_lib():
+    global _COMM_LIB
+    if _COMM_LIB is None:
+        _COMM_LIB = load_comm_library()
+    return _COMM_LIB
+
+
+def check(rc: int, what: str = '') -> None:
+    if rc != 0:
+        msg = _LIB.npm_last_error() if _LIB is not None else b''
+        raise NpmError(f'{what or "npm call"} failed ({rc}): {msg.decode() if msg else ""}')
+
+
+def check_comm(rc: int, what: str = '') -> None:
+    if rc != 0:
+        msg = _COMM_LIB.npm_comm_last_error() if _COMM_LIB is not None else b''
+        raise NpmError(f'{what or "npm_comm call"} failed ({rc}): {msg.decode() if msg else ""}')
+
+
+def device_index() -> Optional[int]:
+    return _DEVICE

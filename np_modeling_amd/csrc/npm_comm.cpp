@@ -1,0 +1,159 @@
+// libnpm_rccl.so: the gradient all-reduce of the data-parallel hot path, on RCCL.
+// xGMI is point-to-point (7 links per GPU), so the exchange is ONE flat bucket per
+// sub-layer group rather than one call per parameter: 16 latency-bound calls would cost
+// more than the 50 MB payload.  See include/npm_comm.h for the contract.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "npm_comm.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code ? code : -1;
+}
+
+struct Comm {
+    bool ready = false;
+    ncclComm_t comm = nullptr;
+    int rank = 0, nranks = 1;
+    hipStream_t compute = nullptr;
+    hipStream_t stream = nullptr;      // communication stream
+    hipEvent_t produced = nullptr;     // compute -> comm
+    hipEvent_t reduced = nullptr;      // comm -> compute
+    double *scalar = nullptr;          // device scratch for host scalar reductions
+} g;
+
+#define HIPC(expr)                                                                  \
+    do {                                                                            \
+        hipError_t _e = (expr);                                                     \
+        if (_e != hipSuccess) return fail((int)_e, "%s: %s -> %s", __func__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define NCCLC(expr)                                                                 \
+    do {                                                                            \
+        ncclResult_t _r = (expr);                                                   \
+        if (_r != ncclSuccess) return fail(20000 + (int)_r, "%s: %s -> %s", __func__, #expr, ncclGetErrorString(_r)); \
+    } while (0)
+
+#define REQUIRE_READY()                                                             \
+    do {                                                                            \
+        if (!g.ready) return fail(-2, "%s: npm_comm_init() has not been called", __func__); \
+    } while (0)
+
+ncclRedOp_t to_op(int op) {
+    switch (op) {
+        case NPM_REDUCE_AVG: return ncclAvg;
+        case NPM_REDUCE_MAX: return ncclMax;
+        default: return ncclSum;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *npm_comm_last_error(void) { return g_err; }
+
+int npm_comm_unique_id(char *id) {
+    if (!id) return fail(-1, "npm_comm_unique_id: null id");
+    static_assert(sizeof(ncclUniqueId) == NPM_COMM_ID_BYTES, "id size");
+    ncclUniqueId uid;
+    NCCLC(ncclGetUniqueId(&uid));
+    memcpy(id, &uid, sizeof(uid));
+    return 0;
+}
+
+int npm_comm_init(const char *id, int rank, int nranks, void *compute_stream) {
+    if (g.ready) return fail(-1, "npm_comm_init: already initialised");
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "npm_comm_init: bad arguments");
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof(uid));
+    NCCLC(ncclCommInitRank(&g.comm, nranks, uid, rank));
+    g.rank = rank;
+    g.nranks = nranks;
+    g.compute = (hipStream_t)compute_stream;
+    HIPC(hipStreamCreateWithFlags(&g.stream, hipStreamNonBlocking));
+    HIPC(hipEventCreateWithFlags(&g.produced, hipEventDisableTiming));
+    HIPC(hipEventCreateWithFlags(&g.reduced, hipEventDisableTiming));
+    HIPC(hipMalloc((void **)&g.scalar, 64));
+    g.ready = true;
+    return 0;
+}
+
+int npm_comm_rank(int *rank, int *nranks) {
+    REQUIRE_READY();
+    if (rank) *rank = g.rank;
+    if (nranks) *nranks = g.nranks;
+    return 0;
+}
+
+int npm_comm_allreduce_f32(float *buf, size_t count, int op) {
+    REQUIRE_READY();
+    if (count == 0) return 0;
+    if (!buf) return fail(-1, "npm_comm_allreduce_f32: null buffer");
+    HIPC(hipEventRecord(g.produced, g.compute));          // gradients written so far ...
+    HIPC(hipStreamWaitEvent(g.stream, g.produced, 0));    // ... are visible to the collective
+    NCCLC(ncclAllReduce(buf, buf, count, ncclFloat32, to_op(op), g.comm, g.stream));
+    return 0;
+}
+
+int npm_comm_broadcast_f32(float *buf, size_t count, int root) {
+    REQUIRE_READY();
+    if (count == 0) return 0;
+    if (!buf) return fail(-1, "npm_comm_broadcast_f32: null buffer");
+    HIPC(hipEventRecord(g.produced, g.compute));
+    HIPC(hipStreamWaitEvent(g.stream, g.produced, 0));
+    NCCLC(ncclBroadcast(buf, buf, count, ncclFloat32, root, g.comm, g.stream));
+    return 0;
+}
+
+int npm_comm_wait(void) {
+    REQUIRE_READY();
+    HIPC(hipEventRecord(g.reduced, g.stream));
+    HIPC(hipStreamWaitEvent(g.compute, g.reduced, 0));
+    return 0;
+}
+
+int npm_comm_barrier(void) {
+    REQUIRE_READY();
+    HIPC(hipStreamSynchronize(g.compute));
+    HIPC(hipMemsetAsync(g.scalar, 0, 8, g.stream));
+    NCCLC(ncclAllReduce(g.scalar, g.scalar, 1, ncclFloat64, ncclSum, g.comm, g.stream));
+    HIPC(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int npm_comm_allreduce_host_f64(double *value, int op) {
+    REQUIRE_READY();
+    if (!value) return fail(-1, "npm_comm_allreduce_host_f64: null value");
+    HIPC(hipMemcpyAsync(g.scalar, value, sizeof(double), hipMemcpyHostToDevice, g.stream));
+    NCCLC(ncclAllReduce(g.scalar, g.scalar, 1, ncclFloat64, to_op(op), g.comm, g.stream));
+    HIPC(hipMemcpyAsync(value, g.scalar, sizeof(double), hipMemcpyDeviceToHost, g.stream));
+    HIPC(hipStreamSynchronize(g.stream));
+    return 0;
+}
+
+int npm_comm_destroy(void) {
+    if (!g.ready) return 0;
+    (void)hipStreamSynchronize(g.stream);
+    (void)ncclCommDestroy(g.comm);
+    (void)hipFree(g.scalar);
+    (void)hipEventDestroy(g.produced);
+    (void)hipEventDestroy(g.reduced);
+    (void)hipStreamDestroy(g.stream);
+    g = Comm();
+    return 0;
+}
+
+}  // extern "C"

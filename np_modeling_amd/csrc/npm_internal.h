@@ -1,0 +1,53 @@
+// Internal helpers shared by the translation units of libnpm_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "npm_hip.h"
+
+namespace npm {
+
+struct Context {
+    bool ready = false;
+    int device = -1;
+    hipStream_t stream = nullptr;
+    int num_cus = 256;
+};
+
+Context &ctx();
+void set_error(const char *fmt, ...);
+int fail(int code, const char *fmt, ...);
+
+// Pool-backed scratch for split-K slabs and reduction partials; released on scope exit.
+// Safe because every launch goes to the single compute stream (stream-ordered reuse).
+struct Scratch {
+    void *ptr = nullptr;
+    int alloc(size_t bytes) { return npm_malloc(&ptr, bytes); }
+    ~Scratch() { if (ptr) npm_free(ptr); }
+};
+
+}  // namespace npm
+
+#define NPM_REQUIRE_INIT()                                                         \
+    do {                                                                           \
+        if (!npm::ctx().ready)                                                     \
+            return npm::fail(NPM_E_NOT_INITIALIZED, "%s: npm_init() has not been called", __func__); \
+    } while (0)
+
+#define NPM_HIP(expr)                                                              \
+    do {                                                                           \
+        hipError_t _e = (expr);                                                    \
+        if (_e != hipSuccess)                                                      \
+            return npm::fail((int)_e, "%s: %s -> %s", __func__, #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+#define NPM_CHECK_LAUNCH() NPM_HIP(hipGetLastError())
+
+#define NPM_ARG(cond)                                                              \
+    do {                                                                           \
+        if (!(cond)) return npm::fail(NPM_E_BAD_ARGUMENT, "%s: bad argument: %s", __func__, #cond); \
+    } while (0)

@@ -1,0 +1,622 @@
+// HBM-bound kernels of the hot path: elementwise ops, column sums and the
+// one-wavefront-per-row softmax / LayerNorm forward and backward.
+//
+// Every kernel streams its operands once with 16-byte loads per lane (64 lanes x 16 B =
+// 1 KiB per wave instruction) and keeps the row in registers between the reduction and
+// the write, so the HBM traffic is the algorithmic minimum (DESIGN.md "Row kernels").
+// Reductions across the 64-lane wavefront use DPP/shuffle butterflies, not LDS.
+#include <algorithm>
+
+#include "npm_internal.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int ROWS_PER_BLOCK = 4;          // 256 threads = 4 waves, one row per wave
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, WAVE);
+    return v;
+}
+
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, WAVE));
+    return v;
+}
+
+inline int grid_for(size_t n_vec, int block = 256, int cap = 8192) {
+    size_t g = (n_vec + block - 1) / block;
+    return (int)std::max<size_t>(1, std::min<size_t>(g, cap));
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+// ---------------------------------------------------------------------------------
+// elementwise: float4 grid-stride body + scalar tail
+// ---------------------------------------------------------------------------------
+template <typename F>
+__global__ void __launch_bounds__(256) ew1_kernel(const float *a, float *out, size_t n, F f) {
+    const size_t nv = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        float4 v = reinterpret_cast<const float4 *>(a)[i];
+        v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
+        reinterpret_cast<float4 *>(out)[i] = v;
+    }
+    for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = f(a[i]);
+}
+
+template <typename F>
+__global__ void __launch_bounds__(256) ew2_kernel(const float *a, const float *b,
+                                                  float *out, size_t n, F f) {
+    const size_t nv = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i];
+        const float4 y = reinterpret_cast<const float4 *>(b)[i];
+        float4 v;
+        v.x = f(x.x, y.x); v.y = f(x.y, y.y); v.z = f(x.z, y.z); v.w = f(x.w, y.w);
+        reinterpret_cast<float4 *>(out)[i] = v;
+    }
+    for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) out[i] = f(a[i], b[i]);
+}
+
+template <typename F>
+__global__ void __launch_bounds__(256) ew3_kernel(const float *a, const float *b,
+                                                  const float *c, float *out, size_t n, F f) {
+    const size_t nv = n / 4;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+        const float4 x = reinterpret_cast<const float4 *>(a)[i];
+        const float4 y = reinterpret_cast<const float4 *>(b)[i];
+        const float4 z = reinterpret_cast<const float4 *>(c)[i];
+        float4 v;
+        v.x = f(x.x, y.x, z.x); v.y = f(x.y, y.y, z.y); v.z = f(x.z, y.z, z.z); v.w = f(x.w, y.w, z.w);
+        reinterpret_cast<float4 *>(out)[i] = v;
+    }
+    for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+        out[i] = f(a[i], b[i], c[i]);
+}
+
+struct ReluF { __device__ float operator()(float x) const { return fmaxf(x, 0.f); } };
+struct ReluBwdF { __device__ float operator()(float x, float dy) const { return x >= 0.f ? dy : 0.f; } };
+struct AddF { __device__ float operator()(float a, float b) const { return a + b; } };
+struct Add3F { __device__ float operator()(float a, float b, float c) const { return (a + b) + c; } };
+struct AxpyF { float alpha; __device__ float operator()(float y, float x) const { return y + alpha * x; } };
+struct ScaleF { float alpha; __device__ float operator()(float x) const { return alpha * x; } };
+struct FillF { float v; __device__ float operator()(float) const { return v; } };
+
+// scalar fallbacks for unaligned pointers
+template <typename F>
+__global__ void ew1_scalar(const float *a, float *out, size_t n, F f) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f(a[i]);
+}
+template <typename F>
+__global__ void ew2_scalar(const float *a, const float *b, float *out, size_t n, F f) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f(a[i], b[i]);
+}
+template <typename F>
+__global__ void ew3_scalar(const float *a, const float *b, const float *c, float *out, size_t n, F f) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) out[i] = f(a[i], b[i], c[i]);
+}
+
+template <typename F>
+int ew1(const float *a, float *out, size_t n, F f) {
+    if (n == 0) return NPM_OK;
+    hipStream_t s = npm::ctx().stream;
+    if (aligned16(a) && aligned16(out)) hipLaunchKernelGGL(ew1_kernel<F>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, out, n, f);
+    else hipLaunchKernelGGL(ew1_scalar<F>, dim3(grid_for(n)), dim3(256), 0, s, a, out, n, f);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+template <typename F>
+int ew2(const float *a, const float *b, float *out, size_t n, F f) {
+    if (n == 0) return NPM_OK;
+    hipStream_t s = npm::ctx().stream;
+    if (aligned16(a) && aligned16(b) && aligned16(out)) hipLaunchKernelGGL(ew2_kernel<F>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, out, n, f);
+    else hipLaunchKernelGGL(ew2_scalar<F>, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n, f);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+template <typename F>
+int ew3(const float *a, const float *b, const float *c, float *out, size_t n, F f) {
+    if (n == 0) return NPM_OK;
+    hipStream_t s = npm::ctx().stream;
+    if (aligned16(a) && aligned16(b) && aligned16(c) && aligned16(out))
+        hipLaunchKernelGGL(ew3_kernel<F>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, c, out, n, f);
+    else hipLaunchKernelGGL(ew3_scalar<F>, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, out, n, f);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// column sum: out[c] = sum_r x[r, c].  Stage 1: grid (col strips of 64, row chunks);
+// 16 threads x float4 cover a 256-B row segment, 16 row lanes per block; partial sums
+// cross the row lanes through LDS.  Stage 2 sums the chunk partials (fixed order).
+// ---------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, long cols, long ld,
+              long rows_per_chunk, long out_ld) {
+    __shared__ float red[16][65];
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const long c0 = (long)blockIdx.x * 64 + cq * 4;
+    const long r_beg = (long)blockIdx.y * rows_per_chunk;
+    const long r_end = min(rows, r_beg + rows_per_chunk);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    const bool full = (c0 + 3 < cols) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    for (long r = r_beg + rl; r < r_end; r += 16) {
+        const float *p = x + r * ld + c0;
+        if (full) {
+            const float4 v = *reinterpret_cast<const float4 *>(p);
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        } else {
+            if (c0 + 0 < cols) acc.x += p[0];
+            if (c0 + 1 < cols) acc.y += p[1];
+            if (c0 + 2 < cols) acc.z += p[2];
+            if (c0 + 3 < cols) acc.w += p[3];
+        }
+    }
+    red[rl][cq * 4 + 0] = acc.x; red[rl][cq * 4 + 1] = acc.y;
+    red[rl][cq * 4 + 2] = acc.z; red[rl][cq * 4 + 3] = acc.w;
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += red[i][threadIdx.x];
+        const long c = (long)blockIdx.x * 64 + threadIdx.x;
+        if (c < cols) out[(long)blockIdx.y * out_ld + c] = s;
+    }
+}
+
+int colsum_impl(const float *x, float *out, long rows, long cols, long ld) {
+    hipStream_t s = npm::ctx().stream;
+    const int strips = (int)((cols + 63) / 64);
+    long chunks = std::max<long>(1, std::min<long>((rows + 255) / 256, std::max<long>(1, 2048 / strips)));
+    const long rpc = (rows + chunks - 1) / chunks;
+    chunks = (rows + rpc - 1) / rpc;
+    if (chunks <= 1) {
+        hipLaunchKernelGGL(colsum_kernel, dim3(strips, 1), dim3(256), 0, s, x, out, rows, cols, ld, std::max<long>(rows, 1), cols);
+        NPM_CHECK_LAUNCH();
+        return NPM_OK;
+    }
+    npm::Scratch part;
+    int rc = part.alloc(sizeof(float) * (size_t)chunks * cols);
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_kernel, dim3(strips, (int)chunks), dim3(256), 0, s, x, (float *)part.ptr, rows, cols, ld, rpc, cols);
+    NPM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(colsum_kernel, dim3(strips, 1), dim3(256), 0, s, (const float *)part.ptr, out, chunks, cols, cols, chunks, cols);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+// ---------------------------------------------------------------------------------
+// Row kernels.  A wave owns a row; lane l holds float4 chunks l, l+64, ... (VPL chunks),
+// i.e. every wave instruction reads 1 KiB contiguous.  VPL is a template so the row
+// lives in registers (n <= 256*VPL).  Rows that are not a multiple of 4 long, or longer
+// than 4096, take the generic re-reading kernels further down.
+// ---------------------------------------------------------------------------------
+template <int VPL>
+__device__ __forceinline__ void load_row(const float *__restrict__ p, int nvec, int lane, float4 (&v)[VPL], float fill) {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = lane + WAVE * j;
+        v[j] = (c < nvec) ? reinterpret_cast<const float4 *>(p)[c] : make_float4(fill, fill, fill, fill);
+    }
+}
+
+template <int VPL>
+__device__ __forceinline__ void store_row(float *__restrict__ p, int nvec, int lane, const float4 (&v)[VPL]) {
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = lane + WAVE * j;
+        if (c < nvec) reinterpret_cast<float4 *>(p)[c] = v[j];
+    }
+}
+
+template <int VPL>
+__global__ void __launch_bounds__(256)
+softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = n >> 2;
+    float4 v[VPL];
+    load_row<VPL>(x + row * n, nvec, lane, v, -INFINITY);
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        v[j].x *= scale; v[j].y *= scale; v[j].z *= scale; v[j].w *= scale;
+        m = fmaxf(m, fmaxf(fmaxf(v[j].x, v[j].y), fmaxf(v[j].z, v[j].w)));
+    }
+    m = wave_max(m);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        v[j].x = expf(v[j].x - m); v[j].y = expf(v[j].y - m);
+        v[j].z = expf(v[j].z - m); v[j].w = expf(v[j].w - m);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) { v[j].x *= inv; v[j].y *= inv; v[j].z *= inv; v[j].w *= inv; }
+    store_row<VPL>(y + row * n, nvec, lane, v);
+}
+
+template <int VPL>
+__global__ void __launch_bounds__(256)
+softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                   long rows, int n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = n >> 2;
+    float4 p[VPL], g[VPL];
+    load_row<VPL>(y + row * n, nvec, lane, p, 0.f);
+    load_row<VPL>(dy + row * n, nvec, lane, g, 0.f);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) dot += (p[j].x * g[j].x + p[j].y * g[j].y) + (p[j].z * g[j].z + p[j].w * g[j].w);
+    dot = wave_sum(dot);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        g[j].x = scale * p[j].x * (g[j].x - dot); g[j].y = scale * p[j].y * (g[j].y - dot);
+        g[j].z = scale * p[j].z * (g[j].z - dot); g[j].w = scale * p[j].w * (g[j].w - dot);
+    }
+    store_row<VPL>(dx + row * n, nvec, lane, g);
+}
+
+// generic (any n, any alignment): re-reads the row; served by L2 after the first pass
+__global__ void __launch_bounds__(256)
+softmax_fwd_generic(const float *__restrict__ x, float *__restrict__ y, long rows, long n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * n;
+    float *yr = y + row * n;
+    float m = -INFINITY;
+    for (long c = lane; c < n; c += WAVE) m = fmaxf(m, scale * xr[c]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (long c = lane; c < n; c += WAVE) s += expf(scale * xr[c] - m);
+    s = wave_sum(s);
+    const float inv = 1.0f / s;
+    for (long c = lane; c < n; c += WAVE) yr[c] = expf(scale * xr[c] - m) * inv;
+}
+
+__global__ void __launch_bounds__(256)
+softmax_bwd_generic(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
+                    long rows, long n, float scale) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *yr = y + row * n, *gr = dy + row * n;
+    float dot = 0.f;
+    for (long c = lane; c < n; c += WAVE) dot += yr[c] * gr[c];
+    dot = wave_sum(dot);
+    for (long c = lane; c < n; c += WAVE) dx[row * n + c] = scale * yr[c] * (gr[c] - dot);
+}
+
+// ---- LayerNorm ---------------------------------------------------------------------
+template <int VPL>
+__global__ void __launch_bounds__(256)
+layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                     float eps, long rows, int d, float *__restrict__ z, float *__restrict__ mean_out,
+                     float *__restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nvec = d >> 2;
+    float4 v[VPL];
+    load_row<VPL>(x + row * d, nvec, lane, v, 0.f);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        if (lane + WAVE * j < nvec) {
+            const float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, e = v[j].w - mean;
+            ss += (a * a + b * b) + (c * c + e * e);
+        }
+    }
+    const float var = wave_sum(ss) / (float)d;          // biased, as np.var
+    const float rstd = 1.0f / sqrtf(var + eps);
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = lane + WAVE * j;
+        if (c < nvec) {
+            const float4 gm = reinterpret_cast<const float4 *>(gamma)[c];
+            const float4 bt = reinterpret_cast<const float4 *>(beta)[c];
+            v[j].x = gm.x * ((v[j].x - mean) * rstd) + bt.x;
+            v[j].y = gm.y * ((v[j].y - mean) * rstd) + bt.y;
+            v[j].z = gm.z * ((v[j].z - mean) * rstd) + bt.z;
+            v[j].w = gm.w * ((v[j].w - mean) * rstd) + bt.w;
+        }
+    }
+    store_row<VPL>(z + row * d, nvec, lane, v);
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+__global__ void __launch_bounds__(256)
+layernorm_fwd_generic(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
+                      float eps, long rows, long d, float *__restrict__ z, float *__restrict__ mean_out,
+                      float *__restrict__ rstd_out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float *xr = x + row * d;
+    float s = 0.f;
+    for (long c = lane; c < d; c += WAVE) s += xr[c];
+    const float mean = wave_sum(s) / (float)d;
+    float ss = 0.f;
+    for (long c = lane; c < d; c += WAVE) { const float a = xr[c] - mean; ss += a * a; }
+    const float var = wave_sum(ss) / (float)d;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    for (long c = lane; c < d; c += WAVE) z[row * d + c] = gamma[c] * ((xr[c] - mean) * rstd) + beta[c];
+    if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
+}
+
+// Backward: each wave walks rows (grid-stride) and keeps its dgamma/dbeta partials for the
+// columns it owns in registers; every wave writes one partial row and a column sum over
+// the wave partials (fixed order, reproducible) finishes the job.
+template <int VPL>
+__global__ void __launch_bounds__(256)
+layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
+                     const float *__restrict__ rstd, const float *__restrict__ gamma,
+                     const float *__restrict__ residual, long rows, int d, float *__restrict__ dx,
+                     float *__restrict__ part_gamma, float *__restrict__ part_beta) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nvec = d >> 2;
+    float4 gm[VPL], dg[VPL], db[VPL];
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = lane + WAVE * j;
+        gm[j] = (c < nvec) ? reinterpret_cast<const float4 *>(gamma)[c] : make_float4(0.f, 0.f, 0.f, 0.f);
+        dg[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float inv_d = 1.0f / (float)d;
+    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
+        float4 g[VPL], yh[VPL];
+        load_row<VPL>(dz + row * d, nvec, lane, g, 0.f);
+        load_row<VPL>(x + row * d, nvec, lane, yh, 0.f);
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const bool on = lane + WAVE * j < nvec;
+            yh[j].x = on ? (yh[j].x - mu) * rs : 0.f; yh[j].y = on ? (yh[j].y - mu) * rs : 0.f;
+            yh[j].z = on ? (yh[j].z - mu) * rs : 0.f; yh[j].w = on ? (yh[j].w - mu) * rs : 0.f;
+            db[j].x += g[j].x; db[j].y += g[j].y; db[j].z += g[j].z; db[j].w += g[j].w;
+            dg[j].x += g[j].x * yh[j].x; dg[j].y += g[j].y * yh[j].y;
+            dg[j].z += g[j].z * yh[j].z; dg[j].w += g[j].w * yh[j].w;
+            g[j].x *= gm[j].x; g[j].y *= gm[j].y; g[j].z *= gm[j].z; g[j].w *= gm[j].w;
+            s1 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+            s2 += (g[j].x * yh[j].x + g[j].y * yh[j].y) + (g[j].z * yh[j].z + g[j].w * yh[j].w);
+        }
+        const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = lane + WAVE * j;
+            float4 o;
+            o.x = rs * (g[j].x - m1 - yh[j].x * m2); o.y = rs * (g[j].y - m1 - yh[j].y * m2);
+            o.z = rs * (g[j].z - m1 - yh[j].z * m2); o.w = rs * (g[j].w - m1 - yh[j].w * m2);
+            if (c < nvec) {
+                if (residual) {
+                    const float4 r = reinterpret_cast<const float4 *>(residual + row * d)[c];
+                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+                }
+                reinterpret_cast<float4 *>(dx + row * d)[c] = o;
+            }
+        }
+    }
+    // one partial row per wave; a column sum over all wave partials finishes dgamma/dbeta
+    const long prow = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+#pragma unroll
+    for (int j = 0; j < VPL; ++j) {
+        const int c = lane + WAVE * j;
+        if (c < nvec) {
+            reinterpret_cast<float4 *>(part_gamma + prow * d)[c] = dg[j];
+            reinterpret_cast<float4 *>(part_beta + prow * d)[c] = db[j];
+        }
+    }
+}
+
+// generic LayerNorm backward: dx only (any d); dgamma/dbeta then come from two column sums
+__global__ void __launch_bounds__(256)
+layernorm_bwd_dx_generic(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
+                         const float *__restrict__ rstd, const float *__restrict__ gamma,
+                         const float *__restrict__ residual, long rows, long d, float *__restrict__ dx,
+                         float *__restrict__ dz_yhat) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mu = mean[row], rs = rstd[row];
+    const float *gr = dz + row * d, *xr = x + row * d;
+    float s1 = 0.f, s2 = 0.f;
+    for (long c = lane; c < d; c += WAVE) {
+        const float yh = (xr[c] - mu) * rs, g = gr[c] * gamma[c];
+        s1 += g; s2 += g * yh;
+    }
+    const float m1 = wave_sum(s1) / (float)d, m2 = wave_sum(s2) / (float)d;
+    for (long c = lane; c < d; c += WAVE) {
+        const float yh = (xr[c] - mu) * rs, g = gr[c] * gamma[c];
+        float o = rs * (g - m1 - yh * m2);
+        if (residual) o += residual[row * d + c];
+        dx[row * d + c] = o;
+        dz_yhat[row * d + c] = gr[c] * yh;
+    }
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int npm_fill_f32(float *dst, float value, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(dst != nullptr || n == 0);
+    return ew1(dst, dst, n, FillF{value});
+}
+
+int npm_relu_fwd(const float *x, float *y, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG((x && y) || n == 0);
+    return ew1(x, y, n, ReluF{});
+}
+
+int npm_relu_bwd(const float *x_pre, const float *dy, float *dx, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG((x_pre && dy && dx) || n == 0);
+    return ew2(x_pre, dy, dx, n, ReluBwdF{});
+}
+
+int npm_add(const float *a, const float *b, float *out, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG((a && b && out) || n == 0);
+    return ew2(a, b, out, n, AddF{});
+}
+
+int npm_add3(const float *a, const float *b, const float *c, float *out, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG((a && b && c && out) || n == 0);
+    return ew3(a, b, c, out, n, Add3F{});
+}
+
+int npm_axpy(float *y, const float *x, float alpha, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG((x && y) || n == 0);
+    return ew2(y, x, y, n, AxpyF{alpha});
+}
+
+int npm_scale(const float *x, float *y, float alpha, size_t n) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG((x && y) || n == 0);
+    return ew1(x, y, n, ScaleF{alpha});
+}
+
+int npm_colsum(const float *x, float *out, int64_t rows, int64_t cols, int64_t ld) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && cols >= 0 && ld >= cols);
+    if (cols == 0) return NPM_OK;
+    NPM_ARG(out != nullptr && (x != nullptr || rows == 0));
+    return colsum_impl(x, out, rows, cols, ld);
+}
+
+#define NPM_ROW_DISPATCH(KERNEL, n, ...)                                                       \
+    do {                                                                                       \
+        const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);                  \
+        if (n <= 256) hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if (n <= 512) hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if (n <= 1024) hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if (n <= 2048) hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);         \
+    } while (0)
+
+int npm_softmax_fwd(const float *x, float *y, int64_t rows, int64_t n, float scale) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && n >= 0);
+    if (rows == 0 || n == 0) return NPM_OK;
+    NPM_ARG(x != nullptr && y != nullptr);
+    NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
+    hipStream_t s = npm::ctx().stream;
+    const bool fast = n % 4 == 0 && n <= 4096 && aligned16(x) && aligned16(y);
+    if (fast) {
+        NPM_ROW_DISPATCH(softmax_fwd_kernel, n, x, y, (long)rows, (int)n, scale);
+    } else {
+        const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(softmax_fwd_generic, dim3(grid), dim3(256), 0, s, x, y, (long)rows, (long)n, scale);
+    }
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_softmax_bwd(const float *y, const float *dy, float *dx, int64_t rows, int64_t n, float scale) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && n >= 0);
+    if (rows == 0 || n == 0) return NPM_OK;
+    NPM_ARG(y != nullptr && dy != nullptr && dx != nullptr);
+    NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
+    hipStream_t s = npm::ctx().stream;
+    const bool fast = n % 4 == 0 && n <= 4096 && aligned16(y) && aligned16(dy) && aligned16(dx);
+    if (fast) {
+        NPM_ROW_DISPATCH(softmax_bwd_kernel, n, y, dy, dx, (long)rows, (int)n, scale);
+    } else {
+        const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(softmax_bwd_generic, dim3(grid), dim3(256), 0, s, y, dy, dx, (long)rows, (long)n, scale);
+    }
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_layernorm_fwd(const float *x, const float *gamma, const float *beta, float eps,
+                      int64_t rows, int64_t d, float *z, float *mean, float *rstd) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && d >= 1);
+    if (rows == 0) return NPM_OK;
+    NPM_ARG(x && gamma && beta && z && mean && rstd);
+    NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
+    hipStream_t s = npm::ctx().stream;
+    const bool fast = d % 4 == 0 && d <= 4096 && aligned16(x) && aligned16(z) && aligned16(gamma) && aligned16(beta);
+    if (fast) {
+        NPM_ROW_DISPATCH(layernorm_fwd_kernel, d, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd);
+    } else {
+        const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+        hipLaunchKernelGGL(layernorm_fwd_generic, dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (long)rows, (long)d, z, mean, rstd);
+    }
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const float *rstd,
+                      const float *gamma, const float *residual, int64_t rows, int64_t d,
+                      float *dx, float *dgamma, float *dbeta) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && d >= 1);
+    NPM_ARG(dgamma != nullptr && dbeta != nullptr);
+    if (rows == 0) {
+        int rc = npm_fill_f32(dgamma, 0.f, (size_t)d);
+        return rc ? rc : npm_fill_f32(dbeta, 0.f, (size_t)d);
+    }
+    NPM_ARG(dz && x && mean && rstd && gamma && dx);
+    hipStream_t s = npm::ctx().stream;
+    const bool fast = d % 4 == 0 && d <= 4096 && aligned16(dz) && aligned16(x) && aligned16(dx) &&
+                      aligned16(gamma) && (residual == nullptr || aligned16(residual));
+    if (fast) {
+        const long row_blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+        const int grid = (int)std::min<long>(row_blocks, 4L * npm::ctx().num_cus);
+        npm::Scratch part;
+        const long prow = (long)grid * ROWS_PER_BLOCK;
+        int rc = part.alloc(sizeof(float) * 2 * (size_t)prow * d);
+        if (rc) return rc;
+        float *pg = (float *)part.ptr, *pb = pg + (size_t)prow * d;
+#define NPM_LNB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pg, pb)
+        if (d <= 256) NPM_LNB(1);
+        else if (d <= 512) NPM_LNB(2);
+        else if (d <= 1024) NPM_LNB(4);
+        else if (d <= 2048) NPM_LNB(8);
+        else NPM_LNB(16);
+#undef NPM_LNB
+        NPM_CHECK_LAUNCH();
+        rc = colsum_impl(pg, dgamma, prow, d, d);
+        if (rc) return rc;
+        return colsum_impl(pb, dbeta, prow, d, d);
+    }
+    NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
+    npm::Scratch tmp;
+    int rc = tmp.alloc(sizeof(float) * (size_t)rows * d);
+    if (rc) return rc;
+    const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    hipLaunchKernelGGL(layernorm_bwd_dx_generic, dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual,
+                       (long)rows, (long)d, dx, (float *)tmp.ptr);
+    NPM_CHECK_LAUNCH();
+    rc = colsum_impl((const float *)tmp.ptr, dgamma, rows, d, d);
+    if (rc) return rc;
+    return colsum_impl(dz, dbeta, rows, d, d);
+}
+
+}  // extern "C"

@@ -1,0 +1,421 @@
+"""``DeviceArray``: an fp32 tensor resident in MI355X HBM, plus typed wrappers over the C ABI.
+
+The reference passes ``np.ndarray`` everywhere and relies on three behaviours that a
+device tensor has to keep:
+
+* parameters are updated IN PLACE by the optimizer (``variable -= lr * gradient``,
+  reference optimizer.py:32) and tests hold aliases to them taken before ``backward``
+  (reference layers/mlp_test.py:50-51,93-94) -> ``__isub__`` mutates device memory and
+  returns ``self``; ``np.asarray(alias)`` always reads the current device contents;
+* array-likes are assigned straight into private attributes (reference
+  layers/utils.py:52-88) -> layers convert lazily with :func:`as_device`;
+* ``copy.deepcopy(layer)`` (reference layers/attentions_test.py:72) -> ``__deepcopy__``.
+
+Anything that is not on the hot path (losses, Adam's fp64 moment math) works through
+``__array__``: the value is copied to the host and NumPy does the arithmetic.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import math
+import numbers
+from typing import Optional, Sequence, Tuple, Union
+
+import numpy as np
+
+from np_modeling_amd import _C
+
+Shape = Tuple[int, ...]
+
+
+def _prod(shape: Sequence[int]) -> int:
+    return int(math.prod(int(s) for s in shape))
+
+
+class _Buffer:
+    """Owns one pool block; returns it to the stream-ordered pool when unreferenced."""
+
+    __slots__ = ('ptr', 'nbytes')
+
+    def __init__(self, nbytes: int):
+        lib = _C.lib()
+        out = C.c_void_p()
+        _C.check(lib.npm_malloc(C.byref(out), max(int(nbytes), 4)), 'npm_malloc')
+        self.ptr = out.value
+        self.nbytes = int(nbytes)
+
+    def __del__(self):
+        ptr, self.ptr = getattr(self, 'ptr', None), None
+        if ptr and _C._LIB is not None:
+            try:
+                _C._LIB.npm_free(ptr)
+            except Exception:       # interpreter shutdown
+                pass
+
+
+class Scaled:
+    """``alpha * array`` kept symbolic so that ``variable -= lr * gradient`` is ONE axpy
+    kernel instead of a temporary plus a subtraction.  Materialises on any other use."""
+
+    __slots__ = ('array', 'alpha')
+
+    def __init__(self, array: 'DeviceArray', alpha: float):
+        self.array = array
+        self.alpha = float(alpha)
+
+    @property
+    def shape(self):
+        return self.array.shape
+
+    @property
+    def size(self):
+        return self.array.size
+
+    dtype = np.dtype(np.float32)
+
+    def materialize(self) -> 'DeviceArray':
+        out = empty(self.array.shape)
+        _C.check(_C.lib().npm_scale(self.array.ptr, out.ptr, self.alpha, self.array.size), 'npm_scale')
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        host = self.array.numpy() * np.float32(self.alpha)
+        return host if dtype is None else host.astype(dtype)
+
+    def __mul__(self, other):
+        if isinstance(other, numbers.Real):
+            return Scaled(self.array, self.alpha * float(other))
+        return np.asarray(self) * other
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return Scaled(self.array, -self.alpha)
+
+
+class DeviceArray:
+    """Contiguous row-major fp32 tensor in device memory (a view into a pool block)."""
+
+    __slots__ = ('_buf', 'ptr', 'shape', '__weakref__')
+    dtype = np.dtype(np.float32)
+    __array_priority__ = 100.0
+
+    def __init__(self, shape: Sequence[int], _buf: Optional[_Buffer] = None, _ptr: Optional[int] = None):
+        self.shape = tuple(int(s) for s in shape)
+        if _buf is None:
+            _buf = _Buffer(4 * _prod(self.shape))
+            _ptr = _buf.ptr
+        self._buf = _buf
+        self.ptr = _ptr
+
+    # ---- metadata ---------------------------------------------------------------
+    @property
+    def size(self) -> int:
+        return _prod(self.shape)
+
+    @property
+    def ndim(self) -> int:
+        return len(self.shape)
+
+    @property
+    def nbytes(self) -> int:
+        return 4 * self.size
+
+    def __len__(self) -> int:
+        if not self.shape:
+            raise TypeError('len() of unsized object')
+        return self.shape[0]
+
+    def __repr__(self) -> str:
+        return f'DeviceArray(shape={self.shape}, dtype=float32, ptr=0x{self.ptr:x})'
+
+    # ---- views --------------------------------------------------------------------
+    def reshape(self, *shape) -> 'DeviceArray':
+        if len(shape) == 1 and not isinstance(shape[0], numbers.Integral):
+            shape = tuple(shape[0])
+        shape = [int(s) for s in shape]
+        if shape.count(-1) > 1:
+            raise ValueError('can only specify one unknown dimension')
+        if -1 in shape:
+            known = _prod([s for s in shape if s != -1])
+            shape[shape.index(-1)] = self.size // known if known else 0
+        if _prod(shape) != self.size:
+            raise ValueError(f'cannot reshape array of size {self.size} into shape {tuple(shape)}')
+        return DeviceArray(shape, self._buf, self.ptr)
+
+    def flat_view(self, offset: int, shape: Sequence[int]) -> 'DeviceArray':
+        """View of ``prod(shape)`` elements starting ``offset`` elements into this array."""
+        n = _prod(shape)
+        if offset < 0 or offset + n > self.size:
+            raise ValueError('flat_view out of range')
+        return DeviceArray(shape, self._buf, self.ptr + 4 * int(offset))
+
+    # ---- host <-> device ----------------------------------------------------------
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, dtype=np.float32)
+        if self.size:
+            _C.check(_C.lib().npm_d2h(out.ctypes.data, self.ptr, out.nbytes), 'npm_d2h')
+        return out
+
+    def __array__(self, dtype=None, copy=None):
+        host = self.numpy()
+        return host if dtype is None or np.dtype(dtype) == np.float32 else host.astype(dtype)
+
+    def set(self, value) -> 'DeviceArray':
+        host = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float32), self.shape))
+        if host.size:
+            _C.check(_C.lib().npm_h2d(self.ptr, host.ctypes.data, host.nbytes), 'npm_h2d')
+        return self
+
+    def copy(self) -> 'DeviceArray':
+        out = DeviceArray(self.shape)
+        if self.size:
+            _C.check(_C.lib().npm_d2d(out.ptr, self.ptr, self.nbytes), 'npm_d2d')
+        return out
+
+    def __copy__(self):
+        return self.copy()
+
+    def __deepcopy__(self, memo):
+        return self.copy()
+
+    def astype(self, dtype, copy=True):
+        if np.dtype(dtype) == np.float32:
+            return self.copy() if copy else self
+        return self.numpy().astype(dtype)
+
+    # ---- in-place updates (the optimizer contract) -----------------------------------
+    def _axpy(self, other, alpha: float) -> 'DeviceArray':
+        if isinstance(other, Scaled):
+            alpha, other = alpha * other.alpha, other.array
+        if isinstance(other, numbers.Real):
+            other = full(self.shape, float(other))
+        elif not isinstance(other, DeviceArray) or other.size != self.size:
+            host = np.asarray(other, dtype=np.float32)
+            other = from_host(np.broadcast_to(host, self.shape))
+        _C.check(_C.lib().npm_axpy(self.ptr, other.ptr, float(alpha), self.size), 'npm_axpy')
+        return self
+
+    def __isub__(self, other):
+        return self._axpy(other, -1.0)
+
+    def __iadd__(self, other):
+        return self._axpy(other, 1.0)
+
+    def __imul__(self, other):
+        if isinstance(other, numbers.Real):
+            _C.check(_C.lib().npm_scale(self.ptr, self.ptr, float(other), self.size), 'npm_scale')
+            return self
+        return self.set(self.numpy() * np.asarray(other))
+
+    # ---- arithmetic ---------------------------------------------------------------------
+    def __mul__(self, other):
+        if isinstance(other, numbers.Real):
+            return Scaled(self, float(other))
+        return self.numpy() * np.asarray(other)
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return Scaled(self, -1.0)
+
+    def __add__(self, other):
+        if isinstance(other, DeviceArray) and other.shape == self.shape:
+            out = empty(self.shape)
+            _C.check(_C.lib().npm_add(self.ptr, other.ptr, out.ptr, self.size), 'npm_add')
+            return out
+        return self.numpy() + np.asarray(other)
+
+    __radd__ = __add__
+
+    def __sub__(self, other):
+        return self.numpy() - np.asarray(other)
+
+    def __rsub__(self, other):
+        return np.asarray(other) - self.numpy()
+
+    def __truediv__(self, other):
+        if isinstance(other, numbers.Real):
+            return Scaled(self, 1.0 / float(other))
+        return self.numpy() / np.asarray(other)
+
+    def __rtruediv__(self, other):
+        return np.asarray(other) / self.numpy()
+
+    def __pow__(self, other):
+        return self.numpy() ** other
+
+    def __getitem__(self, idx):
+        return self.numpy()[idx]
+
+    def __iter__(self):
+        return iter(self.numpy())
+
+    def sum(self, *a, **k):
+        return self.numpy().sum(*a, **k)
+
+    def mean(self, *a, **k):
+        return self.numpy().mean(*a, **k)
+
+    def max(self, *a, **k):
+        return self.numpy().max(*a, **k)
+
+    def min(self, *a, **k):
+        return self.numpy().min(*a, **k)
+
+    def __eq__(self, other):
+        return self.numpy() == np.asarray(other)
+
+    def __ne__(self, other):
+        return self.numpy() != np.asarray(other)
+
+    def __lt__(self, other):
+        return self.numpy() < np.asarray(other)
+
+    def __le__(self, other):
+        return self.numpy() <= np.asarray(other)
+
+    def __gt__(self, other):
+        return self.numpy() > np.asarray(other)
+
+    def __ge__(self, other):
+        return self.numpy() >= np.asarray(other)
+
+    __hash__ = None
+
+
+ArrayLike = Union[DeviceArray, np.ndarray, Sequence]
+
+
+# ---- constructors ------------------------------------------------------------------------
+def empty(shape: Sequence[int]) -> DeviceArray:
+    return DeviceArray(shape)
+
+
+def full(shape: Sequence[int], value: float) -> DeviceArray:
+    out = DeviceArray(shape)
+    if out.size:
+        _C.check(_C.lib().npm_fill_f32(out.ptr, float(value), out.size), 'npm_fill_f32')
+    return out
+
+
+def zeros(shape: Sequence[int]) -> DeviceArray:
+    return full(shape, 0.0)
+
+
+def from_host(value) -> DeviceArray:
+    host = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+    out = DeviceArray(host.shape)
+    if host.size:
+        _C.check(_C.lib().npm_h2d(out.ptr, host.ctypes.data, host.nbytes), 'npm_h2d')
+    return out
+
+
+def as_device(value) -> DeviceArray:
+    """DeviceArray as is; ``Scaled`` materialised; anything else (np.ndarray, jax Array,
+    nested lists) copied to the device as contiguous fp32."""
+    if isinstance(value, DeviceArray):
+        return value
+    if isinstance(value, Scaled):
+        return value.materialize()
+    return from_host(value)
+
+
+def synchronize() -> None:
+    _C.check(_C.lib().npm_sync(), 'npm_sync')
+
+
+def pool_stats() -> Tuple[int, int]:
+    used, reserved = C.c_size_t(), C.c_size_t()
+    _C.check(_C.lib().npm_pool_stats(C.byref(used), C.byref(reserved)))
+    return used.value, reserved.value
+
+
+class Event:
+    """HIP event on the compute stream (bench.py times kernels with these)."""
+
+    def __init__(self):
+        self._h = C.c_void_p()
+        _C.check(_C.lib().npm_event_create(C.byref(self._h)), 'npm_event_create')
+
+    def record(self) -> 'Event':
+        _C.check(_C.lib().npm_event_record(self._h), 'npm_event_record')
+        return self
+
+    def synchronize(self) -> None:
+        _C.check(_C.lib().npm_event_sync(self._h), 'npm_event_sync')
+
+    def elapsed_ms(self, end: 'Event') -> float:
+        ms = C.c_float()
+        _C.check(_C.lib().npm_event_elapsed_ms(self._h, end._h, C.byref(ms)), 'npm_event_elapsed_ms')
+        return float(ms.value)
+
+    def __del__(self):
+        h, self._h = getattr(self, '_h', None), None
+        if h and _C._LIB is not None:
+            try:
+                _C._LIB.npm_event_destroy(h)
+            except Exception:
+                pass
+
+
+# ---- kernel wrappers -------------------------------------------------------------------------
+class Mat:
+    """Operand descriptor for :func:`gemm`: base pointer, row pitch, two batch strides."""
+
+    __slots__ = ('ptr', 'ld', 's0', 's1', '_keep')
+
+    def __init__(self, array_or_ptr, ld: int, s0: int = 0, s1: int = 0):
+        self._keep = array_or_ptr          # keeps a temporary alive until the launch is queued
+        self.ptr = array_or_ptr.ptr if isinstance(array_or_ptr, DeviceArray) else int(array_or_ptr)
+        self.ld, self.s0, self.s1 = int(ld), int(s0), int(s1)
+
+
+def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = False, trans_b: bool = False,
+         batch: Tuple[int, int] = (1, 1), alpha: float = 1.0, bias: Optional[DeviceArray] = None,
+         residual: Optional[Mat] = None, relu_save: Optional[Mat] = None, relu_mask: Optional[Mat] = None,
+         split_k: int = 0) -> None:
+    """C = epilogue(alpha * op(A) @ op(B)); see include/npm_hip.h ``npm_sgemm``."""
+    g = _C.npm_gemm()
+    g.trans_a, g.trans_b = int(trans_a), int(trans_b)
+    g.m, g.n, g.k = int(m), int(n), int(k)
+    g.batch0, g.batch1 = int(batch[0]), int(batch[1])
+    g.a, g.lda, g.stride_a0, g.stride_a1 = a.ptr, a.ld, a.s0, a.s1
+    g.b, g.ldb, g.stride_b0, g.stride_b1 = b.ptr, b.ld, b.s0, b.s1
+    g.c, g.ldc, g.stride_c0, g.stride_c1 = c.ptr, c.ld, c.s0, c.s1
+    g.alpha = float(alpha)
+    epi = 0
+    if bias is not None:
+        epi |= _C.EPI_BIAS
+        g.bias = bias.ptr
+    if residual is not None:
+        epi |= _C.EPI_RESIDUAL
+        g.residual, g.ldr = residual.ptr, residual.ld
+    if relu_save is not None:
+        epi |= _C.EPI_RELU_SAVE
+        g.aux, g.ldaux = relu_save.ptr, relu_save.ld
+    if relu_mask is not None:
+        epi |= _C.EPI_RELU_MASK
+        g.aux, g.ldaux = relu_mask.ptr, relu_mask.ld
+    g.epilogue = epi
+    g.split_k = int(split_k)
+    _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
+
+
+def colsum(x: DeviceArray, rows: int, cols: int, out: Optional[DeviceArray] = None) -> DeviceArray:
+    out = empty([cols]) if out is None else out
+    _C.check(_C.lib().npm_colsum(x.ptr, out.ptr, rows, cols, cols), 'npm_colsum')
+    return out
+
+
+def add(a: DeviceArray, b: DeviceArray, out: Optional[DeviceArray] = None) -> DeviceArray:
+    out = empty(a.shape) if out is None else out
+    _C.check(_C.lib().npm_add(a.ptr, b.ptr, out.ptr, a.size), 'npm_add')
+    return out
+
+
+def add3(a: DeviceArray, b: DeviceArray, c: DeviceArray, out: Optional[DeviceArray] = None) -> DeviceArray:
+    out = empty(a.shape) if out is None else out
+    _C.check(_C.lib().npm_add3(a.ptr, b.ptr, c.ptr, out.ptr, a.size), 'npm_add3')
+    return out

@@ -1,0 +1,197 @@
+"""Multi-head attention on the fp32 MFMA GEMM (reference layers/attentions.py:11-199).
+
+Every einsum of the reference is a GEMM view, addressed in place -- no transposes are
+materialised:
+
+* projections ``'...ab,cdb->...acd'`` (attentions.py:88-100): [B*S, F] x w[H*D, F]^T, bias in
+  the epilogue; q/k/v stay in the reference's [B, S, H, D] layout;
+* ``QK^T`` / ``PV`` and their four gradients (attentions.py:103-112,146-162): GEMMs batched
+  over (B, H) whose operands are head slices of [B, S, H, D] (row pitch H*D, batch strides
+  (S*H*D, D));
+* the context ("values") is written as [B, Sq, H, Dv] so that the output projection
+  ``'...abc,...dac->...bd'`` (attentions.py:116) is a plain [B*Sq, H*Dv] x wo[F, H*Dv]^T GEMM
+  (the reference's own cache is head-major [B, H, Sq, Dv]; this one is private state);
+* softmax forward/backward with the 1/sqrt(Dk) scaling fused (attentions.py:104,150-155).
+
+Parameter layouts are the reference's: wq/wk [H, Dk, H*Dk], wv [H, Dv, H*Dv], wo [H*Dk, H, Dv],
+bq/bk [H, Dk], bv [H, Dv], bo [H*Dk] (attentions.py:46-65), drawn in that order.
+"""
+
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+from np_modeling_amd import device as D
+from np_modeling_amd import parallel
+from np_modeling_amd.device import Mat
+from np_modeling_amd.layers import activations, layer
+
+_PARAMS = ('_wq', '_wk', '_wv', '_wo', '_bq', '_bk', '_bv', '_bo')
+
+
+class MultiHeadAttention(layer.StatefulLayer):
+    def __init__(self, num_heads: int, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._num_heads = num_heads
+        self._softmax = activations.Softmax()
+
+    def initialize(self, query, key=None, value=None, *args, **kwargs) -> None:
+        # query [B, Sq, H*Dk]; key [B, Skv, H*Dk]; value [B, Skv, H*Dv]
+        if key is None:
+            key = query
+        if value is None:
+            value = key
+        assert query.shape[0] == key.shape[0]
+        assert query.shape[2] == key.shape[2]
+        assert query.shape[0] == value.shape[0]
+        assert key.shape[1] == value.shape[1]
+        self._seq_len_q = query.shape[1]
+        self._seq_len_kv = key.shape[1]
+        h = self._num_heads
+        assert key.shape[2] % h == 0
+        self._key_dim = dk = key.shape[2] // h
+        assert value.shape[2] % h == 0
+        self._value_dim = dv = value.shape[2] // h
+        self._wq = self._new_param([h, dk, h * dk])
+        self._wk = self._new_param([h, dk, h * dk])
+        self._wv = self._new_param([h, dv, h * dv])
+        self._wo = self._new_param([h * dk, h, dv])
+        self._bq = self._new_param([h, dk])
+        self._bk = self._new_param([h, dk])
+        self._bv = self._new_param([h, dv])
+        self._bo = self._new_param([h * dk])
+
+    def _numel(self) -> int:
+        return sum(self._param(p).size for p in _PARAMS) + 4 * len(_PARAMS)
+
+    # -- forward -------------------------------------------------------------------------
+    def forward(self, query, key=None, value=None, mask=None):
+        if mask is not None and bool(mask):     # ndarray masks raise ValueError here, as attentions.py:84
+            raise NotImplementedError('attention masks are not supported (reference: attentions.py:152-153)')
+        query = D.as_device(query)
+        key = query if key is None else D.as_device(key)
+        value = key if value is None else D.as_device(value)
+        return self._forward_impl(query, key, value)
+
+    def _forward_impl(self, query, key, value, residual: Optional[D.DeviceArray] = None):
+        h, dk, dv = self._num_heads, self._key_dim, self._value_dim
+        b, sq, f = query.shape
+        skv = key.shape[1]
+        fv = value.shape[2]
+        assert f == h * dk and key.shape == (b, skv, f) and value.shape[:2] == (b, skv) and fv == h * dv
+        wq, wk, wv, wo = (self._param(p) for p in ('_wq', '_wk', '_wv', '_wo'))
+        bq, bk, bv, bo = (self._param(p) for p in ('_bq', '_bk', '_bv', '_bo'))
+        self._query, self._key, self._value, self._mask = query, key, value, None
+
+        # in-projections: [rows, F] x w[H*D, F]^T + b
+        q = D.empty([b, sq, h, dk])
+        k = D.empty([b, skv, h, dk])
+        v = D.empty([b, skv, h, dv])
+        D.gemm(b * sq, h * dk, f, Mat(query, f), Mat(wq, f), Mat(q, h * dk), trans_b=True, bias=bq)
+        D.gemm(b * skv, h * dk, f, Mat(key, f), Mat(wk, f), Mat(k, h * dk), trans_b=True, bias=bk)
+        D.gemm(b * skv, h * dv, fv, Mat(value, fv), Mat(wv, fv), Mat(v, h * dv), trans_b=True, bias=bv)
+        self._q, self._k, self._v = q, k, v
+
+        # attention[b, h] = q_h k_h^T ; scores = softmax(attention / sqrt(dk))
+        scores = D.empty([b, h, sq, skv])
+        D.gemm(sq, skv, dk, Mat(q, h * dk, sq * h * dk, dk), Mat(k, h * dk, skv * h * dk, dk),
+               Mat(scores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))
+        self._scale = 1.0 / math.sqrt(dk)
+        activations.Softmax._run_forward(scores, self._scale, out=scores)
+        self._softmax._y = scores
+        self._attention_scores = scores
+
+        # context[b, :, h, :] = scores[b, h] v_h      -> [B, Sq, H, Dv]
+        ctx = D.empty([b, sq, h, dv])
+        D.gemm(sq, dv, skv, Mat(scores, skv, h * sq * skv, sq * skv), Mat(v, h * dv, skv * h * dv, dv),
+               Mat(ctx, h * dv, sq * h * dv, dv), batch=(b, h))
+        self._context = ctx
+
+        # output projection: [B*Sq, H*Dv] x wo[F, H*Dv]^T + bo (+ skip connection)
+        out = D.empty([b, sq, f])
+        D.gemm(b * sq, f, h * dv, Mat(ctx, h * dv), Mat(wo, h * dv), Mat(out, f), trans_b=True, bias=bo,
+               residual=None if residual is None else Mat(residual, f))
+        return out
+
+    # -- backward --------------------------------------------------------------------------
+    def backward(self, dy, optimizer_):
+        with parallel.grad_scope(self._numel()) as scope:
+            return self._backward_impl(D.as_device(dy), optimizer_, scope)
+
+    def _backward_impl(self, dy, optimizer_, scope, *, sum_inputs: bool = False,
+                       residual: Optional[D.DeviceArray] = None):
+        """Returns (dquery, dkey, dvalue) (attentions.py:199), or -- for a composite that feeds
+        one tensor as query, key and value -- their sum (+ residual) accumulated in the GEMM
+        epilogues when ``sum_inputs`` is set (reference layers/transformer.py:84-85)."""
+        if self._mask:
+            raise NotImplementedError
+        h, dk, dv = self._num_heads, self._key_dim, self._value_dim
+        query, key, value = self._query, self._key, self._value
+        q, k, v, scores, ctx = self._q, self._k, self._v, self._attention_scores, self._context
+        b, sq, f = dy.shape
+        skv, fv = key.shape[1], value.shape[2]
+        wq, wk, wv, wo = (self._param(p) for p in ('_wq', '_wk', '_wv', '_wo'))
+        m_q, m_kv = b * sq, b * skv
+
+        # output projection (attentions.py:129-136)
+        dbo = scope.take([f])
+        D.colsum(dy, m_q, f, out=dbo)
+        dwo = scope.take(wo.shape)
+        D.gemm(f, h * dv, m_q, Mat(dy, f), Mat(ctx, h * dv), Mat(dwo, h * dv), trans_a=True)      # dy^T ctx
+        dctx = D.empty([b, sq, h, dv])
+        D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))                    # dy wo
+
+        # softmax @ V (attentions.py:146-148)
+        assert v.shape == (b, skv, h, dv)
+        dscores = D.empty([b, h, sq, skv])
+        D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
+               Mat(dscores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))             # dctx_h v_h^T
+        dv_ = D.empty([b, skv, h, dv])
+        D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
+               Mat(dv_, h * dv, skv * h * dv, dv), trans_a=True, batch=(b, h))                    # P_h^T dctx_h
+
+        # softmax backward with the 1/sqrt(dk) of attentions.py:155 folded in
+        datt = activations.Softmax._run_backward(scores, dscores, self._scale, out=dscores)
+
+        # Q K^T (attentions.py:161-162)
+        dq = D.empty([b, sq, h, dk])
+        D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, h * dk, skv * h * dk, dk),
+               Mat(dq, h * dk, sq * h * dk, dk), batch=(b, h))                                    # datt_h k_h
+        dk_ = D.empty([b, skv, h, dk])
+        D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, h * dk, sq * h * dk, dk),
+               Mat(dk_, h * dk, skv * h * dk, dk), trans_a=True, batch=(b, h))                    # datt_h^T q_h
+
+        # in-projections (attentions.py:167-188): dw = dproj^T x ; dx = dproj w
+        dwq, dwk, dwv = scope.take(wq.shape), scope.take(wk.shape), scope.take(wv.shape)
+        D.gemm(h * dk, f, m_q, Mat(dq, h * dk), Mat(query, f), Mat(dwq, f), trans_a=True)
+        D.gemm(h * dk, f, m_kv, Mat(dk_, h * dk), Mat(key, f), Mat(dwk, f), trans_a=True)
+        D.gemm(h * dv, fv, m_kv, Mat(dv_, h * dv), Mat(value, fv), Mat(dwv, fv), trans_a=True)
+
+        if sum_inputs:
+            assert query is key and key is value
+            total = D.empty([b, sq, f])
+            D.gemm(m_q, f, h * dk, Mat(dq, h * dk), Mat(wq, f), Mat(total, f),
+                   residual=None if residual is None else Mat(residual, f))
+            D.gemm(m_kv, f, h * dk, Mat(dk_, h * dk), Mat(wk, f), Mat(total, f), residual=Mat(total, f))
+            D.gemm(m_kv, fv, h * dv, Mat(dv_, h * dv), Mat(wv, fv), Mat(total, fv), residual=Mat(total, fv))
+            result = total
+        else:
+            assert residual is None
+            dquery, dkey, dvalue = D.empty([b, sq, f]), D.empty([b, skv, f]), D.empty([b, skv, fv])
+            D.gemm(m_q, f, h * dk, Mat(dq, h * dk), Mat(wq, f), Mat(dquery, f))
+            D.gemm(m_kv, f, h * dk, Mat(dk_, h * dk), Mat(wk, f), Mat(dkey, f))
+            assert value.shape == (b, skv, h * dv) and dv_.shape == (b, skv, h, dv)
+            D.gemm(m_kv, fv, h * dv, Mat(dv_, h * dv), Mat(wv, fv), Mat(dvalue, fv))
+            result = (dquery, dkey, dvalue)
+
+        dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
+        D.colsum(dq, m_q, h * dk, out=dbq)
+        D.colsum(dk_, m_kv, h * dk, out=dbk)
+        D.colsum(dv_, m_kv, h * dv, out=dbv)
+
+        # update order of attentions.py:190-197
+        for attribute, grad in (('_wq', dwq), ('_wk', dwk), ('_wv', dwv), ('_wo', dwo),
+                                ('_bq', dbq), ('_bk', dbk), ('_bv', dbv), ('_bo', dbo)):
+            scope.defer(optimizer_, self, attribute, grad)
+        return result

@@ -1,0 +1,88 @@
+"""LayerNormalization and DropOut (reference layers/normalizations.py:9-75)."""
+
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+
+from np_modeling_amd import _C
+from np_modeling_amd import device as D
+from np_modeling_amd import parallel
+from np_modeling_amd.layers import layer
+
+
+class DropOut(layer.Layer):
+    """``drop_prob == 0`` is the identity and returns its argument unchanged
+    (normalizations.py:14-23) -- the only path the encoder exercises.  For p > 0 the mask is
+    drawn on the host with the reference's exact call (``np.random.binomial``), so a seeded
+    run drops the same elements; the masking itself is host arithmetic (outside the hot
+    path)."""
+
+    def __init__(self, drop_prob: float, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._drop_prob = drop_prob
+
+    def forward(self, x, training: bool = True):
+        if training and self._drop_prob != 0.0:
+            keep = 1 - self._drop_prob
+            self._mask = np.random.binomial(n=1, p=keep, size=x.size).reshape(x.shape)
+            return D.as_device(np.where(self._mask, np.asarray(x) / keep, 0.0))
+        return x
+
+    def backward(self, dl_dy, *args, **kwargs):
+        if self._drop_prob != 0.0:
+            keep = 1 - self._drop_prob
+            return D.as_device(np.where(self._mask, np.asarray(dl_dy) / keep, 0.0))
+        return dl_dy
+
+
+class LayerNormalization(layer.StatefulLayer):
+    """Row-wise normalisation over the last axis with biased variance and epsilon inside the
+    square root (normalizations.py:45-48).  gamma and beta are RANDOM-initialised (not 1/0),
+    gamma first (normalizations.py:40-41).  One wavefront per row; the backward is the closed
+    form of the reference's [rows, d, d] Jacobian einsum (normalizations.py:58-71)."""
+
+    def __init__(self, epsilon: float = 1e-3, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self._epsilon = epsilon
+
+    def initialize(self, x):
+        self._col = x.shape[-1]
+        self._gamma = self._new_param([self._col])
+        self._beta = self._new_param([self._col])
+
+    def forward(self, x):
+        x = D.as_device(x)
+        gamma, beta = self._param('_gamma'), self._param('_beta')
+        d = x.shape[-1]
+        assert gamma.shape == (d,), f'{gamma.shape} vs {d}'
+        rows = x.size // d
+        self._x = x
+        self._mean = D.empty(tuple(x.shape[:-1]) + (1,))
+        self._rstd = D.empty(tuple(x.shape[:-1]) + (1,))
+        z = D.empty(x.shape)
+        _C.check(_C.lib().npm_layernorm_fwd(x.ptr, gamma.ptr, beta.ptr, float(self._epsilon), rows, d,
+                                            z.ptr, self._mean.ptr, self._rstd.ptr), 'npm_layernorm_fwd')
+        return z
+
+    def backward(self, dl_dz, optimizer_):
+        with parallel.grad_scope(2 * self._param('_gamma').size + 8) as scope:
+            return self._backward_impl(D.as_device(dl_dz), optimizer_, scope)
+
+    def _backward_impl(self, dz: D.DeviceArray, optimizer_, scope,
+                       residual: Optional[D.DeviceArray] = None) -> D.DeviceArray:
+        """dx (+ residual), and deferred updates of gamma then beta (normalizations.py:73-74)."""
+        x = self._x
+        gamma = self._param('_gamma')
+        d = x.shape[-1]
+        assert dz.size == x.size, f'{dz.shape} vs {x.shape}'
+        rows = x.size // d
+        dgamma, dbeta = scope.take([d]), scope.take([d])
+        dx = D.empty(dz.shape)
+        _C.check(_C.lib().npm_layernorm_bwd(dz.ptr, x.ptr, self._mean.ptr, self._rstd.ptr, gamma.ptr,
+                                            None if residual is None else residual.ptr, rows, d,
+                                            dx.ptr, dgamma.ptr, dbeta.ptr), 'npm_layernorm_bwd')
+        scope.defer(optimizer_, self, '_gamma', dgamma)
+        scope.defer(optimizer_, self, '_beta', dbeta)
+        return dx

@@ -1,0 +1,260 @@
+"""Data-parallel gradient exchange: batch sharding across the 8 MI355X of a node.
+
+The reference is single-process; this module is the build's one
+exchange step (section 8e): between a layer's gradient computation and its
+``optimizer_.update`` calls (reference layers/mlp.py:38-39, normalizations.py:73-74,
+attentions.py:190-197) the parameter gradients are all-reduced over RCCL/xGMI.
+
+Design
+* one process per GPU (``torch.distributed.run`` sets RANK/LOCAL_RANK/WORLD_SIZE);
+  the 128-byte RCCL id travels through the launcher's TCP store -- the only use of
+  torch in the product, and only when WORLD_SIZE > 1;
+* gradients of one backward are carved out of ONE flat device bucket
+  (:class:`GradScope`), so the exchange is a few large all-reduces issued on a separate
+  communication stream as soon as each sub-layer's gradients exist (overlapping the rest
+  of backward) instead of 16 latency-bound calls;
+* every parameter update of the scope is applied after the exchange.  That is legal for
+  composites because every dx is computed from pre-update weights (reference
+  layers/transformer.py:61-92), so deferring the updates does not change results;
+* reduction is AVG by default: with the reference's unchanged ``MSELoss`` (divides by the
+  LOCAL ``y.size``, loss.py:25,29) the average of per-rank gradients equals the gradient
+  of the global-batch loss.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Callable, List, Optional, Sequence, Tuple
+
+from np_modeling_amd import _C
+from np_modeling_amd import device as D
+
+SUM, AVG, MAX = 0, 1, 2
+
+
+class Communicator:
+    """What a GradScope needs from a transport (RCCL here; tests plug gloo)."""
+
+    rank = 0
+    world_size = 1
+
+    def allreduce_async(self, flat: 'D.DeviceArray', op: int) -> None:
+        raise NotImplementedError
+
+    def wait(self) -> None:
+        raise NotImplementedError
+
+    def barrier(self) -> None:
+        raise NotImplementedError
+
+    def allreduce_scalar(self, value: float, op: int) -> float:
+        raise NotImplementedError
+
+    def broadcast(self, flat: 'D.DeviceArray', root: int = 0) -> None:
+        raise NotImplementedError
+
+    def close(self) -> None:
+        pass
+
+
+class RcclCommunicator(Communicator):
+    """RCCL through libnpm_rccl.so (include/npm_comm.h)."""
+
+    def __init__(self, rank: int, world_size: int, unique_id: bytes):
+        self._lib = _C.comm_lib()
+        self.rank, self.world_size = rank, world_size
+        stream = _C.lib().npm_stream()
+        _C.check_comm(self._lib.npm_comm_init(unique_id, rank, world_size, stream), 'npm_comm_init')
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = C.create_string_buffer(128)
+        _C.check_comm(_C.comm_lib().npm_comm_unique_id(buf), 'npm_comm_unique_id')
+        return buf.raw
+
+    def allreduce_async(self, flat, op):
+        _C.check_comm(self._lib.npm_comm_allreduce_f32(flat.ptr, flat.size, op), 'npm_comm_allreduce_f32')
+
+    def wait(self):
+        _C.check_comm(self._lib.npm_comm_wait(), 'npm_comm_wait')
+
+    def barrier(self):
+        _C.check_comm(self._lib.npm_comm_barrier(), 'npm_comm_barrier')
+
+    def allreduce_scalar(self, value, op):
+        v = C.c_double(float(value))
+        _C.check_comm(self._lib.npm_comm_allreduce_host_f64(C.byref(v), op), 'npm_comm_allreduce_host_f64')
+        return float(v.value)
+
+    def broadcast(self, flat, root=0):
+        _C.check_comm(self._lib.npm_comm_broadcast_f32(flat.ptr, flat.size, root), 'npm_comm_broadcast_f32')
+        self.wait()
+
+    def close(self):
+        self._lib.npm_comm_destroy()
+
+
+_COMM: Optional[Communicator] = None
+_REDUCE_OP = AVG
+
+
+def _exchange_unique_id(rank: int, world_size: int) -> bytes:
+    """Carry rank 0's RCCL id to the other ranks through the launcher's TCP store."""
+    from torch.distributed import TCPStore      # plumbing only; imported only when world_size > 1
+    import datetime
+    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
+    port = int(os.environ['MASTER_PORT'])
+    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '').lower() == 'true'
+    store = TCPStore(addr, port, world_size, is_master=(rank == 0 and not agent_store),
+                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
+    key = 'np_modeling_amd/rccl_id/' + os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+    if rank == 0:
+        uid = RcclCommunicator.new_unique_id()
+        store.set(key, uid)
+    else:
+        uid = bytes(store.get(key))
+    return uid
+
+
+def init(reduce: str = 'avg') -> Communicator:
+    """Join the data-parallel group described by RANK / WORLD_SIZE (idempotent)."""
+    global _COMM, _REDUCE_OP
+    _REDUCE_OP = {'avg': AVG, 'sum': SUM}[reduce]
+    if _COMM is not None:
+        return _COMM
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if world <= 1:
+        _COMM = Communicator()
+        return _COMM
+    _C.lib()                                             # bind this process to cuda:LOCAL_RANK first
+    uid = _exchange_unique_id(rank, world)
+    _COMM = RcclCommunicator(rank, world, uid)
+    return _COMM
+
+
+def set_communicator(comm: Optional[Communicator], reduce: str = 'avg') -> None:
+    """Install a transport explicitly (tests use a gloo transport on host memory)."""
+    global _COMM, _REDUCE_OP
+    _COMM = comm
+    _REDUCE_OP = {'avg': AVG, 'sum': SUM}[reduce]
+
+
+def communicator() -> Communicator:
+    return _COMM if _COMM is not None else Communicator()
+
+
+def world_size() -> int:
+    return communicator().world_size
+
+
+def rank() -> int:
+    return communicator().rank
+
+
+def shutdown() -> None:
+    global _COMM
+    if _COMM is not None:
+        _COMM.close()
+    _COMM = None
+
+
+def shard(array, axis: int = 0):
+    """This rank's contiguous slice of a host batch along ``axis`` (axis 0 of qkv / dy)."""
+    import numpy as np
+    w, r = world_size(), rank()
+    n = array.shape[axis]
+    assert n % w == 0, f'batch {n} is not divisible by world_size {w}'
+    per = n // w
+    index = [slice(None)] * array.ndim
+    index[axis] = slice(r * per, (r + 1) * per)
+    return np.ascontiguousarray(array[tuple(index)])
+
+
+# --------------------------------------------------------------------------------------------
+class GradScope:
+    """Collects the gradients and deferred parameter updates of one ``backward``.
+
+    The outermost scope of a backward owns the flat bucket; nested scopes (sub-layers of a
+    composite) delegate to it.  ``take`` hands out gradient storage, ``defer`` queues an
+    ``optimizer_.update``, ``flush`` starts the all-reduce of everything taken so far, and
+    leaving the outermost scope waits for the exchange and applies the updates in order.
+    """
+
+    _active: Optional['GradScope'] = None
+
+    def __init__(self, numel_hint: int = 0):
+        self._hint = int(numel_hint)
+        self._outer: Optional[GradScope] = None
+        self._bucket: Optional[D.DeviceArray] = None
+        self._offset = 0
+        self._flushed = 0
+        self._loose: List[D.DeviceArray] = []
+        self._updates: List[Tuple[object, object, str, object]] = []
+
+    # -- context management ----------------------------------------------------------
+    def __enter__(self) -> 'GradScope':
+        self._outer = GradScope._active
+        if self._outer is None:
+            GradScope._active = self
+            if world_size() > 1 and self._hint > 0:
+                self._bucket = D.empty([self._hint])
+        return self
+
+    def __exit__(self, exc_type, exc, tb) -> bool:
+        if self._outer is not None:
+            return False
+        GradScope._active = None
+        if exc_type is None:
+            self._finish()
+        return False
+
+    @property
+    def root(self) -> 'GradScope':
+        return self if self._outer is None else self._outer.root
+
+    # -- gradient storage ------------------------------------------------------------------
+    def take(self, shape: Sequence[int]) -> D.DeviceArray:
+        root = self.root
+        n = D._prod(shape)
+        if root._bucket is not None:
+            start = (root._offset + 3) // 4 * 4                # 16-byte aligned slices
+            if start + n <= root._bucket.size:
+                root._offset = start + n
+                return root._bucket.flat_view(start, shape)
+        g = D.empty(shape)
+        if world_size() > 1:
+            root._loose.append(g)
+        return g
+
+    def defer(self, optimizer_, obj, attribute: str, grad) -> None:
+        self.root._updates.append((optimizer_, obj, attribute, grad))
+
+    def flush(self) -> None:
+        """Start exchanging every gradient produced so far (asynchronous)."""
+        root = self.root
+        comm = communicator()
+        if comm.world_size <= 1:
+            return
+        if root._bucket is not None and root._offset > root._flushed:
+            begin = root._flushed
+            comm.allreduce_async(root._bucket.flat_view(begin, [root._offset - begin]), _REDUCE_OP)
+            root._flushed = root._offset
+        for g in root._loose:
+            comm.allreduce_async(g.reshape(-1), _REDUCE_OP)
+        root._loose = []
+
+    def _finish(self) -> None:
+        comm = communicator()
+        if comm.world_size > 1:
+            self.flush()
+            comm.wait()
+        updates, self._updates = self._updates, []
+        for optimizer_, obj, attribute, grad in updates:
+            optimizer_.update(obj, attribute, grad)
+        self._bucket = None
+
+
+def grad_scope(numel_hint: int = 0) -> GradScope:
+    return GradScope(numel_hint)

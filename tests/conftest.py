@@ -25,3 +25,17 @@ def load_golden(name):
 @pytest.fixture
 def golden():
     return load_golden
+
+
+def assert_close(got, ref, tol=1e-5, what=''):
+    """Parity metric of this repo: |got - ref| <= tol * (|ref| + max|ref|) elementwise.
+
+    fp32 GEMMs reorder sums, so an element's error scales with the magnitude of the tensor
+    (the terms that cancelled), not with the element itself; a purely relative test would
+    be meaningless on near-zero elements.  BASELINE.json's bound is 1e-4; most tests use a
+    tighter tol."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    assert got.shape == ref.shape, f'{what}: shape {got.shape} vs {ref.shape}'
+    scale = np.abs(ref).max() if ref.size else 0.0
+    np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * scale + 1e-30, err_msg=what)

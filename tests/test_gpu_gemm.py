@@ -1,0 +1,159 @@
+"""GPU: npm_sgemm (fp32 MFMA GEMM) through the C ABI against NumPy fp64.
+
+Covers every operand layout the hot path uses (NN / NT / TN), ragged and tiny shapes,
+unaligned leading dimensions (scalar staging path), head-strided batched operands,
+all epilogues and split-K."""
+
+import numpy as np
+import pytest
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def D():
+    from np_modeling_amd import device
+    return device
+
+
+def _ref(a, b, ta, tb):
+    a = a.astype(np.float64)
+    b = b.astype(np.float64)
+    return (a.T if ta else a) @ (b.T if tb else b)
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize('m,n,k', [(128, 128, 32), (256, 384, 96), (64, 16, 32), (1, 1, 1), (5, 7, 3),
+                                   (130, 129, 33), (300, 200, 500), (128, 128, 0), (37, 515, 260)])
+def test_layouts_and_shapes(D, ta, tb, m, n, k):
+    rng = np.random.default_rng(m * 1000003 + n * 1009 + k)
+    a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+    da, db, dc = D.from_host(a), D.from_host(b), D.full([m, n], np.nan)
+    D.gemm(m, n, k, D.Mat(da, a.shape[1] if a.ndim == 2 else 1), D.Mat(db, b.shape[1]), D.Mat(dc, n),
+           trans_a=ta, trans_b=tb)
+    assert_close(dc, _ref(a, b, ta, tb), tol=2e-6, what=f'{m}x{n}x{k} ta={ta} tb={tb}')
+
+
+def test_identity_times_asymmetric_is_exact(D):
+    """A = I with an asymmetric B catches a transposed C/D register map; fp32 MFMA is exact here."""
+    n = 160
+    b = (np.arange(n * n, dtype=np.float32).reshape(n, n) % 251) - 100.0
+    dc = D.empty([n, n])
+    D.gemm(n, n, n, D.Mat(D.from_host(np.eye(n, dtype=np.float32)), n), D.Mat(D.from_host(b), n), D.Mat(dc, n))
+    np.testing.assert_array_equal(dc.numpy(), b)
+
+
+def test_matches_fmaf_chain_bitwise_small_k(D):
+    """The f32 MFMA is a k-ordered fmaf chain: with K <= 4 per lane-half group the result is
+    bit-exact against float32 arithmetic done in the kernel's k order (k = 8g + 4h + s)."""
+    rng = np.random.default_rng(0)
+    a = rng.standard_normal((64, 8)).astype(np.float32)
+    b = rng.standard_normal((8, 64)).astype(np.float32)
+    dc = D.empty([64, 64])
+    D.gemm(64, 64, 8, D.Mat(D.from_host(a), 8), D.Mat(D.from_host(b), 64), D.Mat(dc, 64))
+    # MFMA step s consumes k = s (half 0) then k = 4 + s (half 1), accumulating in fp32 fma order
+    acc = np.zeros((64, 64), dtype=np.float64)
+    exact = np.zeros((64, 64), dtype=np.float32)
+    for s in range(4):
+        for kk in (s, 4 + s):
+            prod = a[:, kk:kk + 1].astype(np.float64) * b[kk:kk + 1, :].astype(np.float64)
+            exact = (exact.astype(np.float64) + prod).astype(np.float32)     # fma: one rounding
+    np.testing.assert_array_equal(dc.numpy(), exact)
+
+
+def test_epilogues(D):
+    rng = np.random.default_rng(3)
+    m, n, k = 200, 136, 72
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    bias = rng.standard_normal(n).astype(np.float32)
+    res = rng.standard_normal((m, n)).astype(np.float32)
+    base = 0.5 * _ref(a, b, False, False) + bias + res
+    da, db = D.from_host(a), D.from_host(b)
+    # alpha + bias + residual
+    c = D.empty([m, n])
+    D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(c, n), alpha=0.5, bias=D.from_host(bias),
+           residual=D.Mat(D.from_host(res), n))
+    assert_close(c, base, tol=2e-6)
+    # accumulate in place (residual aliases C)
+    c2 = D.from_host(res)
+    D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(c2, n), alpha=0.5, bias=D.from_host(bias),
+           residual=D.Mat(c2, n))
+    assert_close(c2, base, tol=2e-6)
+    # relu with saved pre-activation
+    pre = D.empty([m, n])
+    y = D.empty([m, n])
+    D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(y, n), bias=D.from_host(bias), relu_save=D.Mat(pre, n))
+    want_pre = _ref(a, b, False, False) + bias
+    assert_close(pre, want_pre, tol=2e-6)
+    np.testing.assert_array_equal(y.numpy(), np.maximum(pre.numpy(), 0.0))
+    # relu mask (x >= 0 passes, including x == 0)
+    mask_src = rng.standard_normal((m, n)).astype(np.float32)
+    mask_src[0, :7] = 0.0
+    out = D.empty([m, n])
+    D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(out, n), relu_mask=D.Mat(D.from_host(mask_src), n))
+    want = np.where(mask_src >= 0, _ref(a, b, False, False), 0.0)
+    assert_close(out, want, tol=2e-6)
+    assert np.all(out.numpy()[0, :7] != 0.0)
+
+
+@pytest.mark.parametrize('split', [0, 1, 3, 7])
+def test_split_k_tall(D, split):
+    """Weight-gradient shape: small M, N and a tall K; slabs are summed in fixed order."""
+    rng = np.random.default_rng(11)
+    m, n, k = 96, 160, 4096 + 40
+    a = rng.standard_normal((k, m)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    c = D.empty([m, n])
+    D.gemm(m, n, k, D.Mat(D.from_host(a), m), D.Mat(D.from_host(b), n), D.Mat(c, n), trans_a=True, split_k=split)
+    assert_close(c, _ref(a, b, True, False), tol=3e-6)
+    c_again = D.empty([m, n])
+    D.gemm(m, n, k, D.Mat(D.from_host(a), m), D.Mat(D.from_host(b), n), D.Mat(c_again, n), trans_a=True,
+           split_k=split)
+    np.testing.assert_array_equal(c.numpy(), c_again.numpy())       # reproducible
+
+
+def test_batched_head_strided(D):
+    """q k^T and p v addressed as head slices of [B, S, H, D] (no transposes)."""
+    rng = np.random.default_rng(5)
+    bsz, h, sq, skv, d = 3, 4, 40, 24, 16
+    q = rng.standard_normal((bsz, sq, h, d)).astype(np.float32)
+    k = rng.standard_normal((bsz, skv, h, d)).astype(np.float32)
+    v = rng.standard_normal((bsz, skv, h, d)).astype(np.float32)
+    dq, dk, dv = D.from_host(q), D.from_host(k), D.from_host(v)
+    s = D.empty([bsz, h, sq, skv])
+    D.gemm(sq, skv, d, D.Mat(dq, h * d, sq * h * d, d), D.Mat(dk, h * d, skv * h * d, d),
+           D.Mat(s, skv, h * sq * skv, sq * skv), trans_b=True, batch=(bsz, h))
+    want = np.einsum('bqhd,bkhd->bhqk', q.astype(np.float64), k.astype(np.float64))
+    assert_close(s, want, tol=2e-6)
+    ctx = D.empty([bsz, sq, h, d])
+    D.gemm(sq, d, skv, D.Mat(s, skv, h * sq * skv, sq * skv), D.Mat(dv, h * d, skv * h * d, d),
+           D.Mat(ctx, h * d, sq * h * d, d), batch=(bsz, h))
+    want_ctx = np.einsum('bhqk,bkhd->bqhd', s.numpy().astype(np.float64), v.astype(np.float64))
+    assert_close(ctx, want_ctx, tol=2e-6)
+    # TN batched: dv = p^T dctx
+    dvv = D.empty([bsz, skv, h, d])
+    D.gemm(skv, d, sq, D.Mat(s, skv, h * sq * skv, sq * skv), D.Mat(ctx, h * d, sq * h * d, d),
+           D.Mat(dvv, h * d, skv * h * d, d), trans_a=True, batch=(bsz, h))
+    want_dv = np.einsum('bhqk,bqhd->bkhd', s.numpy().astype(np.float64), ctx.numpy().astype(np.float64))
+    assert_close(dvv, want_dv, tol=2e-6)
+
+
+def test_large_tile_aligned(D):
+    """A shape that fills the chip (2048 blocks) with tile-aligned fast-path staging."""
+    rng = np.random.default_rng(9)
+    m, n, k = 4096, 1024, 512
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k)).astype(np.float32)
+    c = D.empty([m, n])
+    D.gemm(m, n, k, D.Mat(D.from_host(a), k), D.Mat(D.from_host(b), k), D.Mat(c, n), trans_b=True)
+    assert_close(c, _ref(a, b, False, True), tol=2e-6)
+
+
+def test_bad_arguments_fail_loudly(D):
+    from np_modeling_amd import _C
+    with pytest.raises(_C.NpmError):
+        D.gemm(8, 8, 8, D.Mat(0, 8), D.Mat(0, 8), D.Mat(0, 8))

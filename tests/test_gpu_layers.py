@@ -1,0 +1,260 @@
+"""GPU: the device layers behind the reference's Layer API, against the reference's own
+outputs (tests/golden, produced by oracle/make_golden.py) and against the oracle at the
+shapes the reference's tests use."""
+
+import copy
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def npm():
+    import np_modeling_amd
+    return np_modeling_amd
+
+
+def rand(shape):
+    return np.random.normal(size=shape).astype(np.float32)
+
+
+# ---- Dense / Linear ---------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['dense', 'linear'])
+def test_dense_golden(npm, name):
+    """Flow of reference layers/mlp_test.py:35-94: aliases of w and b taken before backward
+    observe the in-place SGD update."""
+    g = load_golden(name)
+    L = npm.layers
+    layer = L.Dense(units=16) if name == 'dense' else L.Linear(units=16)
+    np.random.seed(0)
+    x = rand([64, 32])
+    y = layer(x)
+    np.testing.assert_array_equal(x, g['x'])
+    lin = layer.linear if name == 'dense' else layer
+    w, b = lin.w, lin.b
+    np.testing.assert_array_equal(np.asarray(w), g['w0'])       # same seeded draws as the reference
+    np.testing.assert_array_equal(np.asarray(b), g['b0'])
+    assert_close(y, g['y'], tol=2e-6)
+    assert y.shape == (64, 16)
+    dx = layer(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert dx.shape == (64, 32)
+    assert_close(dx, g['dx'], tol=2e-6)
+    assert_close(w, g['w1'], tol=2e-6)                           # alias sees the update
+    assert_close(b, g['b1'], tol=2e-6)
+    assert lin.w is w
+
+
+def test_call_protocol(npm):
+    L = npm.layers
+    layer = L.Dense(units=8)
+    x = rand([4, 6])
+    layer(x)
+    with pytest.raises(ValueError):
+        layer(rand([4, 8]), backprop=True, learning_rate=0.1, optimizer_=npm.optimizer.SGDOptimizer(0.1))
+    with pytest.raises(AssertionError):
+        L.Dense(units=3).linear                                  # property asserts _initialized
+    # Linear backward is 2-D only, like reference mlp.py:33
+    lin = L.Linear(units=5)
+    lin(rand([2, 3, 4]))
+    with pytest.raises(AssertionError):
+        lin(rand([2, 3, 5]), backprop=True, learning_rate=0.1)
+    # first call may be a backprop call: initialize still fires (layer.py:33-35)
+    relu = L.ReLU()
+    assert relu._initialized is False
+    relu(x)
+    assert relu._initialized is True
+
+
+def test_array_likes_assigned_into_private_attrs(npm):
+    """Weight binders assign plain arrays into _w/_b (reference layers/utils.py:77-88)."""
+    L = npm.layers
+    layer = L.Dense(units=16)
+    x = rand([10, 12])
+    layer(x)
+    w = rand([12, 16])
+    b = rand([16])
+    layer._linear._w = w.tolist()
+    layer._linear._b = b
+    y = layer(x)
+    want, pre = O.dense_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    assert_close(y, want, tol=2e-6)
+    dy = rand([10, 16])
+    dx = layer(dy, backprop=True, learning_rate=0.5)
+    wdx, wdw, wdb = O.dense_bwd(x.astype(np.float64), w.astype(np.float64), pre, dy.astype(np.float64))
+    assert_close(dx, wdx, tol=2e-6)
+    assert_close(layer.linear.w, w - 0.5 * wdw, tol=2e-6)
+    assert_close(layer.linear.b, b - 0.5 * wdb, tol=2e-6)
+
+
+def test_reference_shaped_optimizer_contract(npm):
+    """An optimizer written like the reference's (getattr -> `v -= lr * g` -> setattr, fp64
+    host moments for Adam) drives the device layers unchanged."""
+    class HostSGD:
+        def __init__(self, lr):
+            self.lr = lr
+
+        def update(self, obj, attribute, gradient):
+            variable = getattr(obj, attribute)
+            variable -= self.lr * gradient
+            setattr(obj, attribute, variable)
+
+    L = npm.layers
+    np.random.seed(3)
+    a, b = L.Dense(units=7), L.Dense(units=7)
+    x, dy = rand([9, 5]), rand([9, 7])
+    np.random.seed(4)
+    a(x)
+    np.random.seed(4)
+    b(x)
+    a(dy, backprop=True, optimizer_=HostSGD(0.1))
+    b(dy, backprop=True, optimizer_=npm.optimizer.SGDOptimizer(0.1))
+    np.testing.assert_array_equal(np.asarray(a.linear.w), np.asarray(b.linear.w))
+    # Adam: same numbers as the oracle's restatement of reference optimizer.py:53-67
+    np.random.seed(4)
+    c = L.Dense(units=7)
+    y = c(x)
+    w0, b0 = np.asarray(c.linear.w).copy(), np.asarray(c.linear.b).copy()
+    adam = npm.optimizer.AdamOptimizer(1e-2)
+    c(dy, backprop=True, optimizer_=adam)
+    _, pre = O.dense_fwd(x, w0, b0)
+    _, dw, db = O.dense_bwd(x, w0, pre, dy)
+    assert_close(c.linear.w, O.adam_step(w0, dw, {}, 1e-2), tol=2e-6)
+    assert_close(c.linear.b, O.adam_step(b0, db, {}, 1e-2), tol=2e-6)
+
+
+# ---- activations ---------------------------------------------------------------------------
+def test_relu_golden(npm):
+    g = load_golden('relu')
+    relu = npm.layers.ReLU()
+    y = relu(g['x'])
+    np.testing.assert_array_equal(np.asarray(y), g['y'])
+    dx = relu.backward(g['dy'])                       # no optimizer argument, as the reference
+    np.testing.assert_array_equal(np.asarray(dx), g['dx'].astype(np.float32))
+    with pytest.raises(AssertionError):
+        relu.backward(g['dy'][:3])
+
+
+def test_softmax_layer(npm):
+    """reference layers/activations_test.py:11-32: [128, 128], backward via __call__ without optimizer."""
+    np.random.seed(0)
+    sm = npm.layers.Softmax()
+    x, dy = rand([128, 128]), rand([128, 128])
+    y = sm(x)
+    assert_close(y, O.softmax_fwd(x.astype(np.float64)), tol=2e-6)
+    dx = sm(dy, backprop=True)
+    assert_close(dx, O.softmax_bwd(np.asarray(y), dy, verbatim=True), tol=5e-6)
+    g = load_golden('softmax')
+    sm3 = npm.layers.Softmax()
+    assert_close(sm3(g['x']), g['y'], tol=2e-6)
+    assert_close(sm3(g['dy'], backprop=True), g['dx'], tol=5e-6)
+
+
+# ---- LayerNormalization ---------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['layernorm_2d', 'layernorm_3d'])
+def test_layernorm_golden(npm, name):
+    g = load_golden(name)
+    eps = float(g['eps'])
+    ln = npm.layers.LayerNormalization(epsilon=eps)
+    np.random.seed(0)
+    x = rand(g['x'].shape) * 2.0 + 0.5
+    z = ln(x)
+    np.testing.assert_array_equal(np.asarray(ln._gamma), g['gamma0'])
+    np.testing.assert_array_equal(np.asarray(ln._beta), g['beta0'])
+    assert_close(z, g['z'], tol=3e-6)
+    gamma, beta = ln._gamma, ln._beta
+    dx = ln(g['dz'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=5e-6)
+    assert_close(gamma, g['gamma1'], tol=3e-6)
+    assert_close(beta, g['beta1'], tol=3e-6)
+
+
+def test_layernorm_rebinding_like_flax_binder(npm):
+    """reference layers/utils.py:62-68 rebinds _gamma/_beta/_epsilon after the first call."""
+    ln = npm.layers.LayerNormalization()
+    x = rand([32, 128])
+    ln(x)
+    assert hasattr(ln, '_gamma') and hasattr(ln, '_beta') and hasattr(ln, '_epsilon')
+    ln._gamma = np.ones(128, dtype=np.float32)
+    ln._beta = np.zeros(128, dtype=np.float32)
+    ln._epsilon = 1e-6
+    z = ln(x)
+    want, _ = O.layernorm_fwd(x.astype(np.float64), np.ones(128), np.zeros(128), 1e-6)
+    assert_close(z, want, tol=3e-6)
+
+
+def test_dropout_identity_and_mask(npm):
+    L = npm.layers
+    d0 = L.DropOut(0.0)
+    x = npm.as_device(rand([8, 8]))
+    assert d0(x) is x                                           # same object (normalizations.py:23)
+    assert d0.backward(x) is x
+    d = L.DropOut(0.5)
+    np.random.seed(0)
+    xs = rand([128, 32])
+    np.random.seed(1)
+    y = np.asarray(d(xs))
+    np.random.seed(1)
+    mask = np.random.binomial(n=1, p=0.5, size=xs.size).reshape(xs.shape)
+    np.testing.assert_allclose(y, np.where(mask, xs / 0.5, 0.0), rtol=1e-6)
+    np.testing.assert_allclose(np.asarray(d.backward(xs)), np.where(mask, xs / 0.5, 0.0), rtol=1e-6)
+
+
+# ---- MultiHeadAttention ------------------------------------------------------------------------
+_MHA = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+
+
+@pytest.mark.parametrize('name', ['mha_self', 'mha_cross'])
+def test_mha_golden(npm, name):
+    g = load_golden(name)
+    layer = npm.layers.MultiHeadAttention(num_heads=int(g['heads']))
+    kv = g.get('kv')
+    out = layer(g['query'], kv) if kv is not None else layer(g['query'])
+    for n in _MHA:                                             # bind the reference's parameters
+        assert getattr(layer, '_' + n).shape == g[n + '0'].shape
+        setattr(layer, '_' + n, g[n + '0'])
+    out = layer(g['query'], kv) if kv is not None else layer(g['query'])
+    assert_close(out, g['out'], tol=1e-5)
+    layer2 = copy.deepcopy(layer)                              # attentions_test.py:72
+    dq, dk, dv = layer2(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dq, g['dquery'], tol=1e-5)
+    assert_close(dk, g['dkey'], tol=1e-5)
+    assert_close(dv, g['dvalue'], tol=1e-5)
+    for n in _MHA:
+        assert_close(getattr(layer2, '_' + n), g[n + '1'], tol=1e-5, what=n)
+        np.testing.assert_array_equal(np.asarray(getattr(layer, '_' + n)), g[n + '0'])   # deepcopy isolated
+
+
+def test_mha_reference_test_shape_vs_oracle(npm):
+    """B16, Sq32, F128, H8 -- reference layers/attentions_test.py:13-85 (self-attention)."""
+    np.random.seed(0)
+    layer = npm.layers.MultiHeadAttention(num_heads=8)
+    query = rand([16, 32, 128])
+    out = layer(query)
+    p = {n: np.asarray(getattr(layer, '_' + n)).astype(np.float64) / (4.0 if n[0] == 'w' else 1.0) for n in _MHA}
+    for n in _MHA:
+        setattr(layer, '_' + n, p[n].astype(np.float32))
+        p[n] = p[n].astype(np.float32).astype(np.float64)
+    out = layer(query)
+    want, cache = O.mha_fwd(p, query.astype(np.float64))
+    assert_close(out, want, tol=1e-5)
+    dy = rand([16, 32, 128]) * 0.01
+    dq, dk, dv = layer(dy, backprop=True, learning_rate=0.01)
+    (wq_, wk_, wv_), grads = O.mha_bwd(p, cache, dy.astype(np.float64))
+    assert_close(np.asarray(dq) + np.asarray(dk) + np.asarray(dv), wq_ + wk_ + wv_, tol=1e-5)
+    for n in _MHA:
+        assert_close(getattr(layer, '_' + n), p[n] - 0.01 * grads[n], tol=1e-5, what=n)
+
+
+def test_mha_mask_conventions(npm):
+    layer = npm.layers.MultiHeadAttention(num_heads=2)
+    q = rand([2, 4, 8])
+    layer(q)
+    with pytest.raises(ValueError):                      # `if mask:` on an ndarray (attentions.py:84)
+        layer(q, mask=np.ones([2, 2, 4, 4]))
+    with pytest.raises(AssertionError):
+        npm.layers.MultiHeadAttention(num_heads=3)(rand([2, 4, 8]))     # 8 % 3 != 0
