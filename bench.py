@@ -1,0 +1,204 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fwd+bwd samples/s of TransformerEncoder d_model=1024, 8 heads, seq=512,
+batch 256 per GPU (BASELINE.json configs[4]; U = 4096 hidden units, pre-norm).
+
+    python bench.py --gpus N --steps K --warmup W
+
+N = 1 runs in this process; for N > 1 the driver launches one rank per GPU with
+``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` and the ranks
+join an RCCL group (batch sharded: every rank runs the per-GPU batch, weak scaling; the
+parameter gradients are all-reduced over xGMI inside ``backward``).
+
+A step = forward + backward + the SGD update of every parameter, on synthetic fp32 tensors
+already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task description) with
+two extra objects: ``roofline`` (the fp32-MFMA GEMM family, algorithmic FLOPs / HIP-event time
+measured over the timed region) and ``cpu_baseline`` (the NumPy oracle on a bounded sample).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def encoder_flops_per_sample(seq, feat, heads, hidden):
+    """2*M*N*K per GEMM, forward + both gradients: 12 projection GEMMs,
+    6 attention GEMMs, 6 feed-forward GEMMs per step."""
+    proj = 12 * 2 * seq * feat * feat
+    attn = 6 * 2 * seq * seq * feat            # heads * (S*S*Dk) = S*S*F
+    ffn = 6 * 2 * seq * feat * hidden
+    return float(proj + attn + ffn)
+
+
+def make_params(rng, feat, heads, hidden):
+    dk = feat // heads
+    s_f, s_h = 1.0 / np.sqrt(feat), 1.0 / np.sqrt(hidden)
+
+    def init(shape, scale=1.0):      # the reference's initializer (N(0,1) clipped), scaled by 1/sqrt(fan_in)
+        return (np.clip(rng.standard_normal(shape, dtype=np.float32), -1, 1) * scale).astype(np.float32)
+
+    return dict(
+        att_wq=init([heads, dk, feat], s_f), att_wk=init([heads, dk, feat], s_f),
+        att_wv=init([heads, dk, feat], s_f), att_wo=init([feat, heads, dk], s_f),
+        att_bq=init([heads, dk]), att_bk=init([heads, dk]), att_bv=init([heads, dk]), att_bo=init([feat]),
+        n1_gamma=init([feat]), n1_beta=init([feat]), n2_gamma=init([feat]), n2_beta=init([feat]),
+        d1_w=init([feat, hidden], s_f), d1_b=init([hidden]), d2_w=init([hidden, feat], s_h), d2_b=init([feat]))
+
+
+def bind(enc, p):
+    att = enc._self_attention
+    for n in ('wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo'):
+        setattr(att, '_' + n, p['att_' + n])
+    enc._norm1._gamma, enc._norm1._beta = p['n1_gamma'], p['n1_beta']
+    enc._norm2._gamma, enc._norm2._beta = p['n2_gamma'], p['n2_beta']
+    enc._dense1._linear._w, enc._dense1._linear._b = p['d1_w'], p['d1_b']
+    enc._dense2._w, enc._dense2._b = p['d2_w'], p['d2_b']
+
+
+def cpu_baseline(args, params):
+    """NumPy oracle (closed-form flavour, BLAS GEMMs) on a bounded sample of the same workload."""
+    from oracle import np_oracle as O
+    b = args.cpu_batch
+    rng = np.random.default_rng(1)
+    qkv = rng.standard_normal([b, args.seq, args.features], dtype=np.float32)
+    dy = rng.standard_normal([b, args.seq, args.features], dtype=np.float32) * np.float32(0.01)
+    p = {k: v.copy() for k, v in params.items()}
+    times = []
+    for _ in range(args.cpu_steps):
+        t0 = time.perf_counter()
+        _, cache = O.encoder_fwd(p, qkv, True)
+        _, grads = O.encoder_bwd(p, cache, dy, True)
+        for k in p:
+            p[k] = O.sgd_step(p[k], grads[k], 1e-4)
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return dict(value=b / best, unit='samples/s', cores=os.cpu_count(), kind='port',
+                sample=f'NumPy oracle (closed-form restatement, OpenBLAS) encoder fwd+bwd+SGD, batch {b} x seq {args.seq} '
+                       f'x d {args.features}, U={args.hidden}, best of {args.cpu_steps} steps ({best:.2f} s/step); '
+                       'the reference-verbatim Jacobian form needs TBs at this width (BASELINE.md)')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=2)
+    ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
+    ap.add_argument('--seq', type=int, default=512)
+    ap.add_argument('--features', type=int, default=1024)
+    ap.add_argument('--heads', type=int, default=8)
+    ap.add_argument('--hidden', type=int, default=4096)
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timer', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    if args.gpus != world:
+        if args.gpus > 1 and world == 1:
+            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
+        args.gpus = world
+
+    import np_modeling_amd as npm
+    from np_modeling_amd import device as D, parallel
+
+    comm = parallel.init('avg')
+    rng = np.random.default_rng(0)                       # identical parameters on every rank
+    params = make_params(rng, args.features, args.heads, args.hidden)
+    data_rng = np.random.default_rng(1000 + rank)        # per-rank shard of the global batch
+    shape = [args.batch, args.seq, args.features]
+    qkv = D.from_host(data_rng.standard_normal(shape, dtype=np.float32))
+    dy = D.from_host(data_rng.standard_normal(shape, dtype=np.float32) * np.float32(0.01))
+
+    enc = npm.layers.TransformerEncoder(num_heads=args.heads, hidden_units=args.hidden, norm_first=True)
+    probe = D.from_host(np.zeros([1, 8, args.features], dtype=np.float32))
+    enc(probe)                                           # lazy initialisation on a tiny input
+    bind(enc, params)
+    sgd = npm.optimizer.SGDOptimizer(1e-4)
+
+    def step():
+        enc(qkv)
+        enc(dy, backprop=True, optimizer_=sgd)
+
+    for _ in range(args.warmup):
+        step()
+    D.synchronize()
+    if world > 1:
+        comm.barrier()
+
+    timer = None if args.no_kernel_timer else D.KernelTimer()
+    if timer is not None:
+        timer.__enter__()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    D.synchronize()
+    if world > 1:
+        comm.barrier()
+    elapsed = time.perf_counter() - t0
+    if timer is not None:
+        timer.__exit__(None, None, None)
+    if world > 1:
+        elapsed = comm.allreduce_scalar(elapsed, parallel.MAX)
+
+    total_samples = args.batch * world * args.steps
+    value = total_samples / elapsed
+    fps = encoder_flops_per_sample(args.seq, args.features, args.heads, args.hidden)
+
+    result = {
+        'metric': 'fwd+bwd samples/sec, TransformerEncoder d=1024 seq=512',
+        'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic N(0,1) fp32 inputs resident in HBM; random-init '
+        'weights (reference initializer scaled by 1/sqrt(fan_in))',
+        'config': {'workload': f'TransformerEncoder fwd+bwd+SGD step, d_model={args.features}, heads={args.heads}, '
+                               f'seq={args.seq}, hidden_units={args.hidden}, pre-norm, batch {args.batch}/GPU '
+                               f'(BASELINE.json configs[4] per-GPU shard; global batch {args.batch * world})',
+                   'global_batch': args.batch * world, 'seq_len': args.seq,
+                   'parallelism': f'dp{world} (batch-sharded, RCCL grad all-reduce)' if world > 1 else 'single GPU'},
+        'step_tflops_per_gpu': value / world * fps / 1e12,
+        'step_frac_of_fp32_mfma_peak': value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+    }
+
+    if timer is not None:
+        summary = timer.summary()
+        gemm = {k: v for k, v in summary.items() if k.startswith('sgemm_')}
+        g_ms = sum(v['ms'] for v in gemm.values())
+        g_flops = sum(v['flops'] for v in gemm.values())
+        g_launches = sum(v['launches'] for v in gemm.values())
+        achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        result['roofline'] = {
+            'kernel': 'sgemm_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family: NN/NT/TN)',
+            'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
+            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'launches': g_launches, 'avg_launch_ms': g_ms / max(g_launches, 1),
+            'share_of_step_time': g_ms / (1e3 * elapsed) if elapsed > 0 else None,
+            'by_layout': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],
+                              'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in sorted(gemm.items())},
+            'hbm_kernels': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],
+                                'GBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
+                            for k, v in sorted(summary.items()) if not k.startswith('sgemm_') and v['ms'] > 0},
+        }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args, params)
+    if rank == 0:
+        print(json.dumps(result))
+    parallel.shutdown()
+
+
+if __name__ == '__main__':
+    main()

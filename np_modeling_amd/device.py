@@ -361,6 +361,54 @@ class Event:
 
 
 # ---- kernel wrappers -------------------------------------------------------------------------
+class KernelTimer:
+    """Brackets every kernel-wrapper call with HIP events on the compute stream and books its
+    ALGORITHMIC work (flops for GEMMs, bytes for the HBM-bound kernels; DESIGN.md has the
+    per-unit figures).  bench.py uses it over the timed region for the roofline object."""
+
+    def __init__(self):
+        self.records = []          # (name, flops, bytes, start, stop)
+
+    def __enter__(self):
+        global _TIMER
+        self._prev, _TIMER = _TIMER, self
+        return self
+
+    def __exit__(self, *exc):
+        global _TIMER
+        _TIMER = self._prev
+        return False
+
+    def summary(self):
+        synchronize()
+        out = {}
+        for name, flops, nbytes, start, stop in self.records:
+            rec = out.setdefault(name, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+            rec['launches'] += 1
+            rec['ms'] += start.elapsed_ms(stop)
+            rec['flops'] += flops
+            rec['bytes'] += nbytes
+        return out
+
+
+_TIMER: Optional[KernelTimer] = None
+
+
+class _timed:
+    __slots__ = ('name', 'flops', 'bytes', 'start')
+
+    def __init__(self, name: str, flops: float = 0.0, nbytes: float = 0.0):
+        self.name, self.flops, self.bytes = name, flops, nbytes
+
+    def __enter__(self):
+        self.start = Event().record() if _TIMER is not None else None
+
+    def __exit__(self, *exc):
+        if self.start is not None and _TIMER is not None:
+            _TIMER.records.append((self.name, self.flops, self.bytes, self.start, Event().record()))
+        return False
+
+
 class Mat:
     """Operand descriptor for :func:`gemm`: base pointer, row pitch, two batch strides."""
 
@@ -400,22 +448,83 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
         g.aux, g.ldaux = relu_mask.ptr, relu_mask.ld
     g.epilogue = epi
     g.split_k = int(split_k)
-    _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
+    layout = 'TN' if trans_a else ('NT' if trans_b else 'NN')
+    with _timed('sgemm_' + layout, flops=2.0 * m * n * k * batch[0] * batch[1]):
+        _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
 
 
 def colsum(x: DeviceArray, rows: int, cols: int, out: Optional[DeviceArray] = None) -> DeviceArray:
     out = empty([cols]) if out is None else out
-    _C.check(_C.lib().npm_colsum(x.ptr, out.ptr, rows, cols, cols), 'npm_colsum')
+    with _timed('colsum', nbytes=4.0 * rows * cols):
+        _C.check(_C.lib().npm_colsum(x.ptr, out.ptr, rows, cols, cols), 'npm_colsum')
     return out
 
 
 def add(a: DeviceArray, b: DeviceArray, out: Optional[DeviceArray] = None) -> DeviceArray:
     out = empty(a.shape) if out is None else out
-    _C.check(_C.lib().npm_add(a.ptr, b.ptr, out.ptr, a.size), 'npm_add')
+    with _timed('add', nbytes=12.0 * a.size):
+        _C.check(_C.lib().npm_add(a.ptr, b.ptr, out.ptr, a.size), 'npm_add')
     return out
 
 
 def add3(a: DeviceArray, b: DeviceArray, c: DeviceArray, out: Optional[DeviceArray] = None) -> DeviceArray:
     out = empty(a.shape) if out is None else out
-    _C.check(_C.lib().npm_add3(a.ptr, b.ptr, c.ptr, out.ptr, a.size), 'npm_add3')
+    with _timed('add3', nbytes=16.0 * a.size):
+        _C.check(_C.lib().npm_add3(a.ptr, b.ptr, c.ptr, out.ptr, a.size), 'npm_add3')
     return out
+
+
+def relu_fwd(x: DeviceArray, out: Optional[DeviceArray] = None) -> DeviceArray:
+    out = empty(x.shape) if out is None else out
+    with _timed('relu_fwd', nbytes=8.0 * x.size):
+        _C.check(_C.lib().npm_relu_fwd(x.ptr, out.ptr, x.size), 'npm_relu_fwd')
+    return out
+
+
+def relu_bwd(x_pre: DeviceArray, dy: DeviceArray, out: Optional[DeviceArray] = None) -> DeviceArray:
+    out = empty(dy.shape) if out is None else out
+    with _timed('relu_bwd', nbytes=12.0 * dy.size):
+        _C.check(_C.lib().npm_relu_bwd(x_pre.ptr, dy.ptr, out.ptr, dy.size), 'npm_relu_bwd')
+    return out
+
+
+def softmax_fwd(x: DeviceArray, scale: float = 1.0, out: Optional[DeviceArray] = None) -> DeviceArray:
+    n = x.shape[-1] if x.ndim else 1
+    rows = x.size // n if n else 0
+    out = empty(x.shape) if out is None else out
+    with _timed('softmax_fwd', nbytes=8.0 * x.size):
+        _C.check(_C.lib().npm_softmax_fwd(x.ptr, out.ptr, rows, n, float(scale)), 'npm_softmax_fwd')
+    return out
+
+
+def softmax_bwd(y: DeviceArray, dy: DeviceArray, scale: float = 1.0, out: Optional[DeviceArray] = None) -> DeviceArray:
+    n = y.shape[-1] if y.ndim else 1
+    rows = y.size // n if n else 0
+    out = empty(y.shape) if out is None else out
+    with _timed('softmax_bwd', nbytes=12.0 * y.size):
+        _C.check(_C.lib().npm_softmax_bwd(y.ptr, dy.ptr, out.ptr, rows, n, float(scale)), 'npm_softmax_bwd')
+    return out
+
+
+def layernorm_fwd(x: DeviceArray, gamma: DeviceArray, beta: DeviceArray, eps: float):
+    """Returns (z, mean, rstd); mean/rstd have x's shape with the last axis reduced to 1."""
+    d = x.shape[-1]
+    rows = x.size // d
+    stat_shape = tuple(x.shape[:-1]) + (1,)
+    z, mean, rstd = empty(x.shape), empty(stat_shape), empty(stat_shape)
+    with _timed('layernorm_fwd', nbytes=8.0 * x.size + 8.0 * rows):
+        _C.check(_C.lib().npm_layernorm_fwd(x.ptr, gamma.ptr, beta.ptr, float(eps), rows, d,
+                                            z.ptr, mean.ptr, rstd.ptr), 'npm_layernorm_fwd')
+    return z, mean, rstd
+
+
+def layernorm_bwd(dz: DeviceArray, x: DeviceArray, mean: DeviceArray, rstd: DeviceArray, gamma: DeviceArray,
+                  dgamma: DeviceArray, dbeta: DeviceArray, residual: Optional[DeviceArray] = None) -> DeviceArray:
+    d = x.shape[-1]
+    rows = x.size // d
+    dx = empty(dz.shape)
+    with _timed('layernorm_bwd', nbytes=(16.0 if residual is not None else 12.0) * x.size + 8.0 * rows):
+        _C.check(_C.lib().npm_layernorm_bwd(dz.ptr, x.ptr, mean.ptr, rstd.ptr, gamma.ptr,
+                                            None if residual is None else residual.ptr, rows, d,
+                                            dx.ptr, dgamma.ptr, dbeta.ptr), 'npm_layernorm_bwd')
+    return dx

@@ -2,7 +2,6 @@
 
 from __future__ import annotations
 
-from np_modeling_amd import _C
 from np_modeling_amd import device as D
 from np_modeling_amd.layers import layer
 
@@ -19,16 +18,12 @@ class ReLU(Activation):
     def forward(self, x):
         x = D.as_device(x)
         self._x = x
-        y = D.empty(x.shape)
-        _C.check(_C.lib().npm_relu_fwd(x.ptr, y.ptr, x.size), 'npm_relu_fwd')
-        return y
+        return D.relu_fwd(x)
 
     def backward(self, dy):
         dy = D.as_device(dy)
         assert dy.shape == self._x.shape, f'{dy.shape} vs {self._x.shape}'
-        dx = D.empty(dy.shape)
-        _C.check(_C.lib().npm_relu_bwd(self._x.ptr, dy.ptr, dx.ptr, dy.size), 'npm_relu_bwd')
-        return dx
+        return D.relu_bwd(self._x, dy)
 
 
 class Softmax(Activation):
@@ -39,25 +34,10 @@ class Softmax(Activation):
     def forward(self, x):
         x = D.as_device(x)
         self._x = x
-        self._y = self._run_forward(x, 1.0)
+        self._y = D.softmax_fwd(x)
         return self._y
 
     def backward(self, dy, *args, **kwargs):
-        return self._run_backward(self._y, D.as_device(dy), 1.0)
-
-    @staticmethod
-    def _run_forward(x, scale, out=None):
-        n = x.shape[-1] if x.ndim else 1
-        rows = x.size // n if n else 0
-        out = D.empty(x.shape) if out is None else out
-        _C.check(_C.lib().npm_softmax_fwd(x.ptr, out.ptr, rows, n, float(scale)), 'npm_softmax_fwd')
-        return out
-
-    @staticmethod
-    def _run_backward(y, dy, scale, out=None):
-        assert dy.shape == y.shape, f'{dy.shape} vs {y.shape}'
-        n = y.shape[-1] if y.ndim else 1
-        rows = y.size // n if n else 0
-        out = D.empty(y.shape) if out is None else out
-        _C.check(_C.lib().npm_softmax_bwd(y.ptr, dy.ptr, out.ptr, rows, n, float(scale)), 'npm_softmax_bwd')
-        return out
+        dy = D.as_device(dy)
+        assert dy.shape == self._y.shape, f'{dy.shape} vs {self._y.shape}'
+        return D.softmax_bwd(self._y, dy)

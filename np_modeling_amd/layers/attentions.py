@@ -98,7 +98,7 @@ class MultiHeadAttention(layer.StatefulLayer):
         D.gemm(sq, skv, dk, Mat(q, h * dk, sq * h * dk, dk), Mat(k, h * dk, skv * h * dk, dk),
                Mat(scores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))
         self._scale = 1.0 / math.sqrt(dk)
-        activations.Softmax._run_forward(scores, self._scale, out=scores)
+        D.softmax_fwd(scores, self._scale, out=scores)
         self._softmax._y = scores
         self._attention_scores = scores
 
@@ -152,7 +152,7 @@ class MultiHeadAttention(layer.StatefulLayer):
                Mat(dv_, h * dv, skv * h * dv, dv), trans_a=True, batch=(b, h))                    # P_h^T dctx_h
 
         # softmax backward with the 1/sqrt(dk) of attentions.py:155 folded in
-        datt = activations.Softmax._run_backward(scores, dscores, self._scale, out=dscores)
+        datt = D.softmax_bwd(scores, dscores, self._scale, out=dscores)
 
         # Q K^T (attentions.py:161-162)
         dq = D.empty([b, sq, h, dk])

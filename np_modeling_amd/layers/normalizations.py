@@ -6,7 +6,6 @@ from typing import Optional
 
 import numpy as np
 
-from np_modeling_amd import _C
 from np_modeling_amd import device as D
 from np_modeling_amd import parallel
 from np_modeling_amd.layers import layer
@@ -57,13 +56,8 @@ class LayerNormalization(layer.StatefulLayer):
         gamma, beta = self._param('_gamma'), self._param('_beta')
         d = x.shape[-1]
         assert gamma.shape == (d,), f'{gamma.shape} vs {d}'
-        rows = x.size // d
         self._x = x
-        self._mean = D.empty(tuple(x.shape[:-1]) + (1,))
-        self._rstd = D.empty(tuple(x.shape[:-1]) + (1,))
-        z = D.empty(x.shape)
-        _C.check(_C.lib().npm_layernorm_fwd(x.ptr, gamma.ptr, beta.ptr, float(self._epsilon), rows, d,
-                                            z.ptr, self._mean.ptr, self._rstd.ptr), 'npm_layernorm_fwd')
+        z, self._mean, self._rstd = D.layernorm_fwd(x, gamma, beta, self._epsilon)
         return z
 
     def backward(self, dl_dz, optimizer_):
@@ -77,12 +71,8 @@ class LayerNormalization(layer.StatefulLayer):
         gamma = self._param('_gamma')
         d = x.shape[-1]
         assert dz.size == x.size, f'{dz.shape} vs {x.shape}'
-        rows = x.size // d
         dgamma, dbeta = scope.take([d]), scope.take([d])
-        dx = D.empty(dz.shape)
-        _C.check(_C.lib().npm_layernorm_bwd(dz.ptr, x.ptr, self._mean.ptr, self._rstd.ptr, gamma.ptr,
-                                            None if residual is None else residual.ptr, rows, d,
-                                            dx.ptr, dgamma.ptr, dbeta.ptr), 'npm_layernorm_bwd')
+        dx = D.layernorm_bwd(dz, x, self._mean, self._rstd, gamma, dgamma, dbeta, residual=residual)
         scope.defer(optimizer_, self, '_gamma', dgamma)
         scope.defer(optimizer_, self, '_beta', dbeta)
         return dx
