@@ -76,7 +76,8 @@ enum {
     NPM_EPI_BIAS = 1,        /* + bias[n]                                  (mlp.py:24) */
     NPM_EPI_RESIDUAL = 2,    /* + residual[m,n] (may alias C: accumulate)  (transformer.py:39,53) */
     NPM_EPI_RELU_SAVE = 4,   /* aux[m,n] = v; C = max(v,0)                 (activations.py:14-15) */
-    NPM_EPI_RELU_MASK = 8    /* C = aux[m,n] >= 0 ? v : 0                  (activations.py:19) */
+    NPM_EPI_RELU_MASK = 8,   /* C = aux[m,n] >= 0 ? v : 0                  (activations.py:19) */
+    NPM_EPI_RELU = 16        /* C = max(v,0), pre-activation not kept (inference) */
 };
 
 typedef struct npm_gemm {
@@ -131,7 +132,7 @@ typedef struct npm_conv2d {
     int32_t relu;
 } npm_conv2d;
 int npm_conv2d_fwd(const npm_conv2d *c);                                           /* conv.py:44-48,97-105 */
-/* dx = conv(dy, flip+transpose(filt))  (conv.py:130,153); mask_pre != NULL applies relu' to dy first */
+/* dx = conv(dy, flip+transpose(filt))  (conv.py:130,153) */
 int npm_conv2d_bwd_x(const float *dy, const float *filt, float *dx,
                      int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
 /* dw[i,j] = shifted(x)^T dy  (conv.py:185-194) */

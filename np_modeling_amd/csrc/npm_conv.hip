@@ -1,23 +1,334 @@
-// Conv2D (NHWC x HWIO, SAME, stride 1, odd k) -- implicit-im2col GEMM.  Placeholder
-// until the implicit-GEMM kernels land: reports NPM_E_UNSUPPORTED (never a CPU fallback).
-#include "npm_internal.h"
+// Conv2D, NHWC x HWIO, 'SAME' padding, stride 1, odd k, as implicit-im2col GEMMs on the
+// fp32 MFMA (reference layers/conv.py:74-194).
+//
+// The reference pads x (conv.py:97), then adds k*k shifted [NHW,C0]x[C0,C1] matmuls
+// (conv.py:101-105); flattening the taps into the contraction index kk = (i*k + j)*C0 + c
+// gives ONE GEMM  y[NHW, C1] = A[NHW, k*k*C0] . filt[k*k*C0, C1]  whose A operand is never
+// built: the tile loader computes, per 16-byte chunk, which input pixel/channel it is and
+// reads x directly (out-of-image taps are zero: the padding).  In NHWC the row index m of the
+// GEMM IS the linear pixel index, so a tap is the pixel m + di*W + dj.
+//   forward : A = gather(x), K-major (channels contiguous)          B = filt [K, C1]
+//   grad_x  : same kernel on dy with the flipped, channel-transposed filter (conv.py:130,153)
+//   grad_w  : dw[k*k*C0, C1] = gather(x)^T dy; A is M-major (K = pixel index), split-K over
+//             the N*H*W pixels with a fixed-order slab reduction (conv.py:185-194)
+// Tile machinery (LDS layouts, MFMA loop, epilogue) is shared with npm_gemm.hip.
+#include <algorithm>
+
+#include "npm_mfma_tile.h"
+
+namespace {
+
+using namespace npm_tile;
+
+struct ConvArgs {
+    const float *X;      // gathered activation [NB, H, W, C]
+    const float *F;      // dense operand: filter [K, N] (fwd) or dy [pixels, N] (grad_w)
+    int H, W, C, ks, pad;
+    int M, N, K;         // GEMM view
+    int tiles_m, tiles_n, splits, k_per_split, group_m;
+    long slab;
+    Epilogue e;
+};
+
+// ---- forward / grad_x: A(m, kk) = X[pixel m shifted by tap(kk)][c(kk)] ----------------------
+template <bool VEC>
+__device__ __forceinline__ void gather_rows(const ConvArgs &p, int m0, int k0, int tid,
+                                            const int (&ph)[4], const int (&pw)[4], float4 (&r)[4]) {
+    const int kk = k0 + (tid & 7) * 4;
+    if (VEC) {
+        // C % 4 == 0: the 4 consecutive kk share one tap
+        const int tap = kk / p.C, c = kk - tap * p.C;
+        const int ti = tap / p.ks, tj = tap - ti * p.ks;
+        const int di = ti - p.pad, dj = tj - p.pad;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            const int hh = ph[i] + di, ww = pw[i] + dj;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < p.M && kk < p.K && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                v = *reinterpret_cast<const float4 *>(p.X + ((long)m + di * p.W + dj) * p.C + c);
+            r[i] = v;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            float e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kj = kk + j;
+                const int tap = kj / p.C, c = kj - tap * p.C;
+                const int ti = tap / p.ks, tj = tap - ti * p.ks;
+                const int di = ti - p.pad, dj = tj - p.pad;
+                const int hh = ph[i] + di, ww = pw[i] + dj;
+                e[j] = (m < p.M && kj < p.K && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                           ? p.X[((long)m + di * p.W + dj) * p.C + c] : 0.f;
+            }
+            r[i] = make_float4(e[0], e[1], e[2], e[3]);
+        }
+    }
+}
+
+template <bool VEC>
+__global__ void __launch_bounds__(NTHREADS)
+conv_fwd_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+    float *sA = smem, *sB = smem + TILE_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    int ph[4], pw[4];           // (h, w) of this thread's 4 gather rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        pw[i] = m % p.W;
+        ph[i] = (m / p.W) % p.H;
+    }
+    const int nkt = (p.K + BK - 1) / BK;
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float4 ra[4], rb[4];
+    gather_rows<VEC>(p, m0, 0, tid, ph, pw, ra);
+    load_tile<false, VEC>(p.F, p.N, n0, p.N, 0, p.K, tid, rb);
+    store_tile<true>(sA, tid, ra);
+    store_tile<false>(sB, tid, rb);
+    __syncthreads();
+    const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            gather_rows<VEC>(p, m0, (kt + 1) * BK, tid, ph, pw, ra);
+            load_tile<false, VEC>(p.F, p.N, n0, p.N, (kt + 1) * BK, p.K, tid, rb);
+        }
+        mma_tile<true, false>(sA, sB, arow, brow, half, acc);
+        __syncthreads();
+        if (more) {
+            store_tile<true>(sA, tid, ra);
+            store_tile<false>(sB, tid, rb);
+        }
+        __syncthreads();
+    }
+    write_tile(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+}
+
+// ---- grad_w: A(kidx = pixel, m' = (tap, c0)) = X[pixel shifted by tap][c0], M-major ---------
+template <bool VEC>
+__global__ void __launch_bounds__(NTHREADS)
+conv_wgrad_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
+    float *sA = smem, *sB = smem + TILE_FLOATS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int t = logical % tiles, split = logical / tiles;
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg + BK - 1) / BK;
+
+    // this thread's 4 consecutive m' = (tap, c): fixed for the whole K loop
+    const int mq = m0 + (tid & 31) * 4;
+    int tdi[4], tdj[4], tc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int mj = mq + j;
+        const int tap = mj / p.C;
+        tc[j] = mj - tap * p.C;
+        const int ti = tap / p.ks;
+        tdi[j] = ti - p.pad;
+        tdj[j] = tap - ti * p.ks - p.pad;
+    }
+    auto gather = [&](int k0, float4 (&r)[4]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int pix = k0 + (tid >> 5) + 8 * i;
+            const int w = pix % p.W, h = (pix / p.W) % p.H;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (pix < kend) {
+                if (VEC) {
+                    const int hh = h + tdi[0], ww = w + tdj[0];
+                    if (mq < p.M && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                        v = *reinterpret_cast<const float4 *>(p.X + ((long)pix + tdi[0] * p.W + tdj[0]) * p.C + tc[0]);
+                } else {
+                    float e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const int hh = h + tdi[j], ww = w + tdj[j];
+                        e[j] = (mq + j < p.M && (unsigned)hh < (unsigned)p.H && (unsigned)ww < (unsigned)p.W)
+                                   ? p.X[((long)pix + tdi[j] * p.W + tdj[j]) * p.C + tc[j]] : 0.f;
+                    }
+                    v = make_float4(e[0], e[1], e[2], e[3]);
+                }
+            }
+            r[i] = v;
+        }
+    };
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    float4 ra[4], rb[4];
+    gather(kbeg, ra);
+    load_tile<false, VEC>(p.F, p.N, n0, p.N, kbeg, kend, tid, rb);
+    store_tile<false>(sA, tid, ra);
+    store_tile<false>(sB, tid, rb);
+    __syncthreads();
+    const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    for (int kt = 0; kt < nkt; ++kt) {
+        const bool more = kt + 1 < nkt;
+        if (more) {
+            gather(kbeg + (kt + 1) * BK, ra);
+            load_tile<false, VEC>(p.F, p.N, n0, p.N, kbeg + (kt + 1) * BK, kend, tid, rb);
+        }
+        mma_tile<false, false>(sA, sB, arow, brow, half, acc);
+        __syncthreads();
+        if (more) {
+            store_tile<false>(sA, tid, ra);
+            store_tile<false>(sB, tid, rb);
+        }
+        __syncthreads();
+    }
+    Epilogue e = p.e;
+    if (p.splits > 1) {
+        e.ws += (long)split * p.slab;
+        write_tile(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
+    } else {
+        write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+    }
+}
+
+// out[(ti, tj, c1), c0] = filt[ks-1-ti, ks-1-tj, c0, c1]      (conv.py:130)
+__global__ void flip_transpose_filter_kernel(const float *__restrict__ filt, float *__restrict__ out,
+                                             int ks, int c0, int c1) {
+    const int total = ks * ks * c0 * c1;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int o0 = idx % c0;
+        const int o1 = (idx / c0) % c1;
+        const int tap = idx / (c0 * c1);
+        const int ti = tap / ks, tj = tap - ti * ks;
+        out[idx] = filt[((long)((ks - 1 - ti) * ks + (ks - 1 - tj)) * c0 + o0) * c1 + o1];
+    }
+}
+
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
+                  const Epilogue &e) {
+    const long m = (long)nb * h * w;
+    NPM_ARG(m < (1L << 31) - BM);
+    ConvArgs a{};
+    a.X = x; a.F = filt_kn;
+    a.H = h; a.W = w; a.C = c; a.ks = ks; a.pad = ks / 2;
+    a.M = (int)m; a.N = n_out; a.K = ks * ks * c;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.splits = 1; a.k_per_split = a.K; a.group_m = 8;
+    a.e = e;
+    const long grid = (long)a.tiles_m * a.tiles_n;
+    NPM_ARG(grid < (1L << 31));
+    const bool vec = c % 4 == 0 && n_out % 4 == 0 && aligned16(x) && aligned16(filt_kn);
+    hipStream_t s = npm::ctx().stream;
+    if (vec) hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+}  // namespace
 
 extern "C" {
 
 int npm_conv2d_fwd(const npm_conv2d *c) {
     NPM_REQUIRE_INIT();
-    (void)c;
-    return npm::fail(NPM_E_UNSUPPORTED, "npm_conv2d_fwd: not built yet");
+    NPM_ARG(c != nullptr);
+    NPM_ARG(c->n >= 0 && c->h >= 1 && c->w >= 1 && c->c_in >= 1 && c->c_out >= 1);
+    NPM_ARG(c->ksize >= 1 && c->ksize % 2 == 1);            // conv.py:94
+    if (c->n == 0) return NPM_OK;
+    NPM_ARG(c->x && c->filt && c->y);
+    Epilogue e{};
+    e.C = c->y; e.ldc = c->c_out; e.alpha = 1.f;
+    if (c->bias) { e.flags |= NPM_EPI_BIAS; e.bias = c->bias; }
+    if (c->relu) {
+        if (c->pre) { e.flags |= NPM_EPI_RELU_SAVE; e.aux = c->pre; e.ldaux = c->c_out; }
+        else e.flags |= NPM_EPI_RELU;
+    }
+    return run_conv_gemm(c->x, c->filt, c->n, c->h, c->w, c->c_in, c->c_out, c->ksize, e);
 }
 
-int npm_conv2d_bwd_x(const float *, const float *, float *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) {
+int npm_conv2d_bwd_x(const float *dy, const float *filt, float *dx,
+                     int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize) {
     NPM_REQUIRE_INIT();
-    return npm::fail(NPM_E_UNSUPPORTED, "npm_conv2d_bwd_x: not built yet");
+    NPM_ARG(n >= 0 && h >= 1 && w >= 1 && c_in >= 1 && c_out >= 1 && ksize >= 1 && ksize % 2 == 1);
+    if (n == 0) return NPM_OK;
+    NPM_ARG(dy && filt && dx);
+    npm::Scratch flipped;
+    const size_t fsz = (size_t)ksize * ksize * c_in * c_out;
+    int rc = flipped.alloc(sizeof(float) * fsz);
+    if (rc) return rc;
+    hipLaunchKernelGGL(flip_transpose_filter_kernel, dim3((int)std::min<size_t>((fsz + 255) / 256, 1024)), dim3(256), 0,
+                       npm::ctx().stream, filt, (float *)flipped.ptr, ksize, c_in, c_out);
+    NPM_CHECK_LAUNCH();
+    Epilogue e{};
+    e.C = dx; e.ldc = c_in; e.alpha = 1.f;
+    return run_conv_gemm(dy, (const float *)flipped.ptr, n, h, w, c_out, c_in, ksize, e);
 }
 
-int npm_conv2d_bwd_w(const float *, const float *, float *, int32_t, int32_t, int32_t, int32_t, int32_t, int32_t) {
+int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
+                     int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize) {
     NPM_REQUIRE_INIT();
-    return npm::fail(NPM_E_UNSUPPORTED, "npm_conv2d_bwd_w: not built yet");
+    NPM_ARG(n >= 0 && h >= 1 && w >= 1 && c_in >= 1 && c_out >= 1 && ksize >= 1 && ksize % 2 == 1);
+    NPM_ARG(dw != nullptr);
+    const long pixels = (long)n * h * w;
+    NPM_ARG(pixels < (1L << 31) - BK);
+    if (pixels == 0) return npm_fill_f32(dw, 0.f, (size_t)ksize * ksize * c_in * c_out);
+    NPM_ARG(dy && x);
+    ConvArgs a{};
+    a.X = x; a.F = dy;
+    a.H = h; a.W = w; a.C = c_in; a.ks = ksize; a.pad = ksize / 2;
+    a.M = ksize * ksize * c_in; a.N = c_out; a.K = (int)pixels;
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.N + BN - 1) / BN;
+    a.group_m = 8;
+    const long tiles = (long)a.tiles_m * a.tiles_n;
+    const int nkt = (a.K + BK - 1) / BK;
+    int splits = 1;
+    if (tiles < 2L * npm::ctx().num_cus && nkt >= 16)
+        splits = (int)std::min<long>((3L * npm::ctx().num_cus + tiles - 1) / tiles, nkt / 8);
+    splits = std::max(1, splits);
+    const int kt_per = (nkt + splits - 1) / splits;
+    splits = (nkt + kt_per - 1) / kt_per;
+    a.splits = splits;
+    a.k_per_split = kt_per * BK;
+    a.e.C = dw; a.e.ldc = c_out; a.e.alpha = 1.f;
+    npm::Scratch ws;
+    if (splits > 1) {
+        a.slab = (long)a.M * a.N;
+        int rc = ws.alloc(sizeof(float) * (size_t)a.slab * splits);
+        if (rc) return rc;
+        a.e.ws = (float *)ws.ptr;
+    }
+    const bool vec = c_in % 4 == 0 && c_out % 4 == 0 && aligned16(x) && aligned16(dy);
+    hipStream_t s = npm::ctx().stream;
+    const int grid = (int)(tiles * splits);
+    if (vec) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(NTHREADS), 0, s, a);
+    else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(NTHREADS), 0, s, a);
+    NPM_CHECK_LAUNCH();
+    if (splits > 1) {
+        ReduceArgs r{};
+        r.ws = a.e.ws; r.slab = a.slab; r.splits = splits;
+        r.M = a.M; r.N = a.N; r.batch1 = 1;
+        r.e = a.e;
+        return launch_splitk_reduce(r, s);
+    }
+    return NPM_OK;
 }
 
 }  // extern "C"

@@ -24,104 +24,23 @@
 //     them in a fixed order: bitwise reproducible, no float atomics.
 #include <algorithm>
 
-#include "npm_internal.h"
+#include "npm_mfma_tile.h"
 
 namespace {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128;
-constexpr int BN = 128;
-constexpr int BK = 32;
-constexpr int KPITCH = 36;          // floats; K-major LDS row pitch
-constexpr int NTHREADS = 256;
-constexpr int TILE_FLOATS = BM * KPITCH;   // >= BK * BM, one operand tile
+using namespace npm_tile;
 
 struct GemmArgs {
     const float *A, *B;
-    float *C;
-    long lda, ldb, ldc;
+    long lda, ldb;
     long sA0, sA1, sB0, sB1, sC0, sC1;
     int M, N, K;
     int batch1;
     int tiles_m, tiles_n, splits, k_per_split;
     int group_m;
-    float alpha;
-    int epi;
-    const float *bias;
-    const float *R;
-    long ldr;
-    float *aux;
-    long ldaux;
-    float *ws;       // split-K slabs: [split][batch][M][N]
-    long slab;       // batch * M * N
+    long slab;       // split-K: batch * M * N
+    Epilogue e;
 };
-
-// Global -> registers for one 128 x 32 operand tile (4 float4 per thread).
-template <bool KMAJ, bool VEC>
-__device__ __forceinline__ void load_tile(const float *__restrict__ base, long ld, int mn0, int MN,
-                                          int k0, int kend, int tid, float4 (&r)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        int mn, k;
-        long off;
-        if (KMAJ) {
-            mn = mn0 + (tid >> 3) + 32 * i;          // row of the tile
-            k = k0 + (tid & 7) * 4;                  // 4 consecutive k
-            off = (long)mn * ld + k;
-        } else {
-            k = k0 + (tid >> 5) + 8 * i;             // k row of the tile
-            mn = mn0 + (tid & 31) * 4;               // 4 consecutive m/n
-            off = (long)k * ld + mn;
-        }
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (VEC) {
-            if (mn < MN && k < kend) v = *reinterpret_cast<const float4 *>(base + off);
-        } else {
-            if (KMAJ) {
-                if (mn < MN) {
-                    if (k + 0 < kend) v.x = base[off + 0];
-                    if (k + 1 < kend) v.y = base[off + 1];
-                    if (k + 2 < kend) v.z = base[off + 2];
-                    if (k + 3 < kend) v.w = base[off + 3];
-                }
-            } else {
-                if (k < kend) {
-                    if (mn + 0 < MN) v.x = base[off + 0];
-                    if (mn + 1 < MN) v.y = base[off + 1];
-                    if (mn + 2 < MN) v.z = base[off + 2];
-                    if (mn + 3 < MN) v.w = base[off + 3];
-                }
-            }
-        }
-        r[i] = v;
-    }
-}
-
-template <bool KMAJ>
-__device__ __forceinline__ void store_tile(float *__restrict__ s, int tid, const float4 (&r)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        if (KMAJ) {
-            const int row = (tid >> 3) + 32 * i;
-            *reinterpret_cast<float4 *>(s + row * KPITCH + (tid & 7) * 4) = r[i];
-        } else {
-            const int k = (tid >> 5) + 8 * i;
-            *reinterpret_cast<float4 *>(s + k * BM + (tid & 31) * 4) = r[i];
-        }
-    }
-}
-
-// Fragment for k-group g (8 k values): 4 floats, element s is k = 8g + 4*half + s.
-template <bool KMAJ>
-__device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int row, int g, int half) {
-    if (KMAJ) {
-        return *reinterpret_cast<const float4 *>(s + row * KPITCH + 8 * g + 4 * half);
-    } else {
-        const float *p = s + (8 * g + 4 * half) * BM + row;
-        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
-    }
-}
 
 template <bool A_KMAJ, bool B_KMAJ, bool VEC>
 __global__ void __launch_bounds__(NTHREADS)
@@ -136,29 +55,15 @@ sgemm_mfma_kernel(const GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l32 = lane & 31, half = lane >> 5;
 
-    // ---- block -> (batch, split, tile) with an XCD-contiguous, bijective remap ----
-    const int nwg = gridDim.x;
-    int logical;
-    {
-        const int bid = blockIdx.x;
-        const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-        logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-    }
+    // block -> (batch z, split, tile): tiles fastest so that neighbours share operand panels
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tiles = p.tiles_m * p.tiles_n;
-    int t = logical % tiles;
+    const int t = logical % tiles;
     const int rest = logical / tiles;
     const int split = rest % p.splits;
     const int z = rest / p.splits;
     int tm, tn;
-    {
-        const int per_group = p.group_m * p.tiles_n;
-        const int gid = t / per_group;
-        const int first = gid * p.group_m;
-        const int gsz = min(p.tiles_m - first, p.group_m);
-        const int in_group = t - gid * per_group;
-        tm = first + in_group % gsz;
-        tn = in_group / gsz;
-    }
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
     const int m0 = tm * BM, n0 = tn * BN;
     const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
     const float *A = p.A + z0 * p.sA0 + z1 * p.sA1;
@@ -169,12 +74,7 @@ sgemm_mfma_kernel(const GemmArgs p) {
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
     f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    zero_acc(acc);
 
     float4 ra[4], rb[4];
     load_tile<A_KMAJ, VEC>(A, p.lda, m0, p.M, kbeg, kend, tid, ra);
@@ -193,22 +93,7 @@ sgemm_mfma_kernel(const GemmArgs p) {
             load_tile<A_KMAJ, VEC>(A, p.lda, m0, p.M, k0, kend, tid, ra);
             load_tile<B_KMAJ, VEC>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
         }
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            const float4 a0 = read_frag<A_KMAJ>(sA, arow, g, half);
-            const float4 a1 = read_frag<A_KMAJ>(sA, arow + 32, g, half);
-            const float4 b0 = read_frag<B_KMAJ>(sB, brow, g, half);
-            const float4 b1 = read_frag<B_KMAJ>(sB, brow + 32, g, half);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
-        }
+        mma_tile<A_KMAJ, B_KMAJ>(sA, sB, arow, brow, half, acc);
         __syncthreads();
         if (more) {
             store_tile<A_KMAJ>(sA, tid, ra);
@@ -217,72 +102,17 @@ sgemm_mfma_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3)+8*(r>>2)+4*half
+    Epilogue e = p.e;
     if (p.splits > 1) {
-        float *W = p.ws + (long)split * p.slab + (long)z * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int col = n0 + wn * 64 + j * 32 + l32;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (row < p.M && col < p.N) W[(long)row * p.N + col] = acc[i][j][r];
-                }
-            }
+        e.ws += (long)split * p.slab + (long)z * p.M * p.N;
+        write_tile(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
         return;
     }
     const long coff = z0 * p.sC0 + z1 * p.sC1;
-    float *C = p.C + coff;
-    const float *R = p.R ? p.R + coff : nullptr;
-    float *aux = p.aux ? p.aux + coff : nullptr;
-    const bool has_bias = (p.epi & NPM_EPI_BIAS) != 0;
-    const bool has_res = (p.epi & NPM_EPI_RESIDUAL) != 0;
-    const bool relu_save = (p.epi & NPM_EPI_RELU_SAVE) != 0;
-    const bool relu_mask = (p.epi & NPM_EPI_RELU_MASK) != 0;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l32;
-            const float bias = (has_bias && col < p.N) ? p.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (row < p.M && col < p.N) {
-                    float v = p.alpha * acc[i][j][r] + bias;
-                    if (has_res) v += R[(long)row * p.ldr + col];
-                    if (relu_save) {
-                        aux[(long)row * p.ldaux + col] = v;
-                        v = fmaxf(v, 0.f);
-                    }
-                    if (relu_mask) v = (aux[(long)row * p.ldaux + col] >= 0.f) ? v : 0.f;
-                    C[(long)row * p.ldc + col] = v;
-                }
-            }
-        }
-}
-
-// Sum the split-K slabs in split order and apply the (linear) epilogue.
-__global__ void __launch_bounds__(256)
-splitk_reduce_kernel(const GemmArgs p, int batch) {
-    const long mn = (long)p.M * p.N;
-    const long total = mn * batch;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-         idx += (long)gridDim.x * blockDim.x) {
-        const int z = (int)(idx / mn);
-        const long e = idx - (long)z * mn;
-        const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
-        float s = 0.f;
-        for (int sp = 0; sp < p.splits; ++sp) s += p.ws[(long)sp * p.slab + idx];
-        float v = p.alpha * s;
-        if (p.epi & NPM_EPI_BIAS) v += p.bias[col];
-        const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
-        const long coff = z0 * p.sC0 + z1 * p.sC1;
-        if (p.epi & NPM_EPI_RESIDUAL) v += p.R[coff + (long)row * p.ldr + col];
-        p.C[coff + (long)row * p.ldc + col] = v;
-    }
+    e.C += coff;
+    if (e.R) e.R += coff;
+    if (e.aux) e.aux += coff;
+    write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
 
 inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
@@ -296,6 +126,36 @@ void launch(const GemmArgs &a, bool vec, int grid, hipStream_t stream) {
 }
 
 }  // namespace
+
+namespace npm_tile {
+
+__global__ void __launch_bounds__(256) splitk_reduce_kernel(const ReduceArgs p) {
+    const long mn = (long)p.M * p.N;
+    const long total = p.slab;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        const int z = (int)(idx / mn);
+        const long el = idx - (long)z * mn;
+        const int row = (int)(el / p.N), col = (int)(el - (long)row * p.N);
+        float s = 0.f;
+        for (int sp = 0; sp < p.splits; ++sp) s += p.ws[(long)sp * p.slab + idx];
+        float v = p.e.alpha * s;
+        if (p.e.flags & NPM_EPI_BIAS) v += p.e.bias[col];
+        const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
+        const long coff = z0 * p.sC0 + z1 * p.sC1;
+        if (p.e.flags & NPM_EPI_RESIDUAL) v += p.e.R[coff + (long)row * p.e.ldr + col];
+        p.e.C[coff + (long)row * p.e.ldc + col] = v;
+    }
+}
+
+int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
+    const int grid = (int)std::min<long>((r.slab + 255) / 256, 8192);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(grid), dim3(256), 0, stream, r);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+}  // namespace npm_tile
 
 extern "C" int npm_sgemm(const npm_gemm *g) {
     NPM_REQUIRE_INIT();
@@ -314,8 +174,8 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (!a_kmaj && b_kmaj) return npm::fail(NPM_E_UNSUPPORTED, "npm_sgemm: trans_a && trans_b is not used by the hot path");
 
     GemmArgs a{};
-    a.A = g->a; a.B = g->b; a.C = g->c;
-    a.lda = g->lda; a.ldb = g->ldb; a.ldc = g->ldc;
+    a.A = g->a; a.B = g->b; a.e.C = g->c;
+    a.lda = g->lda; a.ldb = g->ldb; a.e.ldc = g->ldc;
     a.sA0 = g->stride_a0; a.sA1 = g->stride_a1;
     a.sB0 = g->stride_b0; a.sB1 = g->stride_b1;
     a.sC0 = g->stride_c0; a.sC1 = g->stride_c1;
@@ -323,13 +183,13 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.batch1 = g->batch1;
     a.tiles_m = (g->m + BM - 1) / BM;
     a.tiles_n = (g->n + BN - 1) / BN;
-    a.alpha = g->alpha;
-    a.epi = epi;
-    a.bias = g->bias;
-    a.R = (epi & NPM_EPI_RESIDUAL) ? g->residual : nullptr;
-    a.ldr = g->ldr;
-    a.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) ? g->aux : nullptr;
-    a.ldaux = g->ldaux;
+    a.e.alpha = g->alpha;
+    a.e.flags = epi;
+    a.e.bias = g->bias;
+    a.e.R = (epi & NPM_EPI_RESIDUAL) ? g->residual : nullptr;
+    a.e.ldr = g->ldr;
+    a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) ? g->aux : nullptr;
+    a.e.ldaux = g->ldaux;
     a.group_m = 8;
 
     const long batch = (long)g->batch0 * g->batch1;
@@ -338,7 +198,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     // Split-K: only for the linear epilogues, when the grid cannot fill 256 CUs x 2-3 blocks.
     int splits = 1;
     const int nkt = (g->k + BK - 1) / BK;
-    const bool linear_epi = !(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK));
+    const bool linear_epi = !(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_RELU));
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
@@ -359,7 +219,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
         a.slab = batch * (long)g->m * g->n;
         int rc = ws.alloc(sizeof(float) * (size_t)a.slab * splits);
         if (rc) return rc;
-        a.ws = (float *)ws.ptr;
+        a.e.ws = (float *)ws.ptr;
     }
 
     // float4 staging needs 16-B aligned rows in both operands.
@@ -378,10 +238,11 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     NPM_CHECK_LAUNCH();
 
     if (splits > 1) {
-        const long total = a.slab;
-        const int rgrid = (int)std::min<long>((total + 255) / 256, 8192);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rgrid), dim3(256), 0, stream, a, (int)batch);
-        NPM_CHECK_LAUNCH();
+        ReduceArgs r{};
+        r.ws = a.e.ws; r.slab = a.slab; r.splits = splits;
+        r.M = a.M; r.N = a.N; r.batch1 = a.batch1; r.sC0 = a.sC0; r.sC1 = a.sC1;
+        r.e = a.e;
+        return launch_splitk_reduce(r, stream);
     }
     return NPM_OK;
 }

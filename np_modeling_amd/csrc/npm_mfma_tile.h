@@ -1,0 +1,208 @@
+// Shared device code of the fp32-MFMA tile kernels (GEMM and implicit-GEMM convolution):
+// 128x128 block tile, K step 32, 4 wavefronts as 2x2, 64x64 per wave = 2x2 MFMA 32x32 tiles.
+// See npm_gemm.hip for the design notes.
+#pragma once
+
+#include "npm_internal.h"
+
+namespace npm_tile {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;
+constexpr int BN = 128;
+constexpr int BK = 32;
+constexpr int KPITCH = 36;                  // floats; K-major LDS row pitch (conflict-free ds_read_b128)
+constexpr int NTHREADS = 256;
+constexpr int TILE_FLOATS = BM * KPITCH;    // >= BK * BM: one operand tile in either layout
+
+// Output side of a launch: where C goes and what the epilogue does.
+struct Epilogue {
+    float *C;
+    long ldc;
+    float alpha;
+    int flags;               // NPM_EPI_*
+    const float *bias;
+    const float *R;          // residual, same indexing as C
+    long ldr;
+    float *aux;              // pre-activation out (RELU_SAVE) / mask in (RELU_MASK)
+    long ldaux;
+    float *ws;               // split-K slabs (raw accumulators), pitch N
+};
+
+// Bijective XCD-contiguous remap: blocks b and b+8 share an XCD (and its L2), so give each
+// XCD one contiguous run of logical tiles.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+}
+
+// tile index -> (tm, tn), column-major inside groups of `group_m` tile rows.
+__device__ __forceinline__ void tile_coords(int t, int tiles_m, int tiles_n, int group_m, int &tm, int &tn) {
+    const int per_group = group_m * tiles_n;
+    const int gid = t / per_group;
+    const int first = gid * group_m;
+    const int gsz = min(tiles_m - first, group_m);
+    const int in_group = t - gid * per_group;
+    tm = first + in_group % gsz;
+    tn = in_group / gsz;
+}
+
+// Registers -> LDS for one 128 x 32 operand tile held as 4 float4 per thread.
+//   K-major : thread holds rows (tid>>3) + 32 i, k = 4 (tid&7) .. +3      -> s[row][k], pitch 36
+//   MN-major: thread holds k rows (tid>>5) + 8 i, mn = 4 (tid&31) .. +3   -> s[k][mn], pitch 128
+template <bool KMAJ>
+__device__ __forceinline__ void store_tile(float *__restrict__ s, int tid, const float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (KMAJ) {
+            const int row = (tid >> 3) + 32 * i;
+            *reinterpret_cast<float4 *>(s + row * KPITCH + (tid & 7) * 4) = r[i];
+        } else {
+            const int k = (tid >> 5) + 8 * i;
+            *reinterpret_cast<float4 *>(s + k * BM + (tid & 31) * 4) = r[i];
+        }
+    }
+}
+
+// Fragment for k-group g (8 k values): element s is k = 8g + 4*half + s.
+template <bool KMAJ>
+__device__ __forceinline__ float4 read_frag(const float *__restrict__ s, int row, int g, int half) {
+    if (KMAJ) {
+        return *reinterpret_cast<const float4 *>(s + row * KPITCH + 8 * g + 4 * half);
+    } else {
+        const float *p = s + (8 * g + 4 * half) * BM + row;
+        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+    }
+}
+
+__device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+}
+
+// The 64 MFMAs of one K tile for one wave.
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void mma_tile(const float *__restrict__ sA, const float *__restrict__ sB,
+                                         int arow, int brow, int half, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int g = 0; g < BK / 8; ++g) {
+        const float4 a0 = read_frag<A_KMAJ>(sA, arow, g, half);
+        const float4 a1 = read_frag<A_KMAJ>(sA, arow + 32, g, half);
+        const float4 b0 = read_frag<B_KMAJ>(sB, brow, g, half);
+        const float4 b1 = read_frag<B_KMAJ>(sB, brow + 32, g, half);
+        const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+    }
+}
+
+// C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half.
+// `raw` stores the accumulators into a split-K slab (pitch N); otherwise the full epilogue.
+__device__ __forceinline__ void write_tile(const f32x16 (&acc)[2][2], const Epilogue &e, bool raw,
+                                           int m0, int n0, int M, int N, int wm, int wn, int l32, int half) {
+    if (raw) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int col = n0 + wn * 64 + j * 32 + l32;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (row < M && col < N) e.ws[(long)row * N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    const bool has_bias = (e.flags & NPM_EPI_BIAS) != 0;
+    const bool has_res = (e.flags & NPM_EPI_RESIDUAL) != 0;
+    const bool relu_save = (e.flags & NPM_EPI_RELU_SAVE) != 0;
+    const bool relu_mask = (e.flags & NPM_EPI_RELU_MASK) != 0;
+    const bool relu = (e.flags & NPM_EPI_RELU) != 0;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l32;
+            const float bias = (has_bias && col < N) ? e.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < M && col < N) {
+                    float v = e.alpha * acc[i][j][r] + bias;
+                    if (has_res) v += e.R[(long)row * e.ldr + col];
+                    if (relu_save) {
+                        e.aux[(long)row * e.ldaux + col] = v;
+                        v = fmaxf(v, 0.f);
+                    }
+                    if (relu_mask) v = (e.aux[(long)row * e.ldaux + col] >= 0.f) ? v : 0.f;
+                    if (relu) v = fmaxf(v, 0.f);
+                    e.C[(long)row * e.ldc + col] = v;
+                }
+            }
+        }
+}
+
+// Dense operand tile: global -> registers (4 float4 per thread), zero-filled outside
+// [0, MN) x [0, kend).  VEC needs 16-byte aligned rows and MN / K multiples of 4.
+template <bool KMAJ, bool VEC>
+__device__ __forceinline__ void load_tile(const float *__restrict__ base, long ld, int mn0, int MN,
+                                          int k0, int kend, int tid, float4 (&r)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        int mn, k;
+        long off;
+        if (KMAJ) {
+            mn = mn0 + (tid >> 3) + 32 * i;
+            k = k0 + (tid & 7) * 4;
+            off = (long)mn * ld + k;
+        } else {
+            k = k0 + (tid >> 5) + 8 * i;
+            mn = mn0 + (tid & 31) * 4;
+            off = (long)k * ld + mn;
+        }
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (VEC) {
+            if (mn < MN && k < kend) v = *reinterpret_cast<const float4 *>(base + off);
+        } else if (KMAJ) {
+            if (mn < MN) {
+                if (k + 0 < kend) v.x = base[off + 0];
+                if (k + 1 < kend) v.y = base[off + 1];
+                if (k + 2 < kend) v.z = base[off + 2];
+                if (k + 3 < kend) v.w = base[off + 3];
+            }
+        } else {
+            if (k < kend) {
+                if (mn + 0 < MN) v.x = base[off + 0];
+                if (mn + 1 < MN) v.y = base[off + 1];
+                if (mn + 2 < MN) v.z = base[off + 2];
+                if (mn + 3 < MN) v.w = base[off + 3];
+            }
+        }
+        r[i] = v;
+    }
+}
+
+// Sum split-K slabs in split order and apply the linear part of the epilogue.
+struct ReduceArgs {
+    const float *ws;
+    long slab;          // elements per split = batch * M * N
+    int splits, M, N, batch1;
+    long sC0, sC1;
+    Epilogue e;
+};
+
+int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream);
+
+}  // namespace npm_tile

@@ -1,0 +1,121 @@
+"""GPU: Conv2D (implicit-im2col MFMA GEMM) against the reference's outputs and the oracle."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_close, load_golden
+from oracle import np_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def npm():
+    import np_modeling_amd
+    return np_modeling_amd
+
+
+def rand(shape):
+    return np.random.normal(size=shape).astype(np.float32)
+
+
+@pytest.mark.parametrize('name,shape,channels,k', [('conv_k3', [3, 9, 7, 8], 12, 3), ('conv_k5', [2, 8, 8, 4], 6, 5),
+                                                   ('conv_k1', [2, 6, 5, 8], 4, 1)])
+def test_conv_golden(npm, name, shape, channels, k):
+    """Flow of reference layers/conv_test.py:37-107 at fixture size, seeded like make_golden.py."""
+    g = load_golden(name)
+    np.random.seed(0)
+    layer = npm.layers.Conv2D(channels=channels, kernel_size=k)
+    x = rand(shape)
+    y = layer(x)
+    w, b = layer.w, layer.b
+    np.testing.assert_array_equal(np.asarray(w), g['w0'])
+    np.testing.assert_array_equal(np.asarray(b), g['b0'])
+    assert_close(y, g['y'], tol=3e-6)
+    dx = layer(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=3e-6)
+    assert_close(w, g['w1'], tol=3e-6)          # aliases observe the in-place update (conv_test.py:57-58)
+    assert_close(b, g['b1'], tol=3e-6)
+
+
+@pytest.mark.parametrize('n,h,w,c0,c1,k', [(1, 1, 1, 1, 1, 1), (2, 5, 4, 3, 5, 3), (1, 7, 9, 6, 10, 5),
+                                           (64, 32, 16, 32, 16, 3),       # reference conv_test.py shape
+                                           (2, 16, 16, 64, 128, 3),       # C3 channel counts, small image
+                                           (3, 6, 6, 20, 132, 1), (1, 3, 40, 8, 8, 7)])
+def test_conv_kernels_vs_oracle(npm, n, h, w, c0, c1, k):
+    from np_modeling_amd import _C, device as D
+    lib = _C.lib()
+    rng = np.random.default_rng(n * 131 + h * 17 + c0 + k)
+    x = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    filt = rng.standard_normal((k, k, c0, c1)).astype(np.float32)
+    bias = rng.standard_normal(c1).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, c1)).astype(np.float32)
+    dx_, df, db, ddy = D.from_host(x), D.from_host(filt), D.from_host(bias), D.from_host(dy)
+    y, pre = D.empty([n, h, w, c1]), D.empty([n, h, w, c1])
+    desc = _C.npm_conv2d(n=n, h=h, w=w, c_in=c0, c_out=c1, ksize=k, x=dx_.ptr, filt=df.ptr, bias=db.ptr,
+                         y=y.ptr, pre=pre.ptr, relu=1)
+    _C.check(lib.npm_conv2d_fwd(C.byref(desc)))
+    want_y, want_pre = O.conv_layer_fwd(x.astype(np.float64), filt.astype(np.float64), bias.astype(np.float64))
+    assert_close(pre, want_pre, tol=3e-6)
+    np.testing.assert_array_equal(y.numpy(), np.maximum(pre.numpy(), 0))
+    # relu without the saved pre-activation, no bias
+    y2 = D.empty([n, h, w, c1])
+    desc2 = _C.npm_conv2d(n=n, h=h, w=w, c_in=c0, c_out=c1, ksize=k, x=dx_.ptr, filt=df.ptr, bias=None,
+                          y=y2.ptr, pre=None, relu=1)
+    _C.check(lib.npm_conv2d_fwd(C.byref(desc2)))
+    assert_close(y2, np.maximum(O.conv2d_fwd(x.astype(np.float64), filt.astype(np.float64)), 0), tol=3e-6)
+    gx, gw = D.empty([n, h, w, c0]), D.empty([k, k, c0, c1])
+    _C.check(lib.npm_conv2d_bwd_x(ddy.ptr, df.ptr, gx.ptr, n, h, w, c0, c1, k))
+    _C.check(lib.npm_conv2d_bwd_w(ddy.ptr, dx_.ptr, gw.ptr, n, h, w, c0, c1, k))
+    assert_close(gx, O.conv2d_grad_x(dy.astype(np.float64), filt.astype(np.float64)), tol=3e-6)
+    assert_close(gw, O.conv2d_grad_w(dy.astype(np.float64), x.astype(np.float64), k), tol=5e-6)
+
+
+def test_conv_rejects_even_kernel(npm):
+    layer = npm.layers.Conv2D(channels=4, kernel_size=2)
+    with pytest.raises(AssertionError):
+        layer(rand([1, 4, 4, 3]))
+    with pytest.raises(AssertionError):
+        npm.layers.Conv2D(channels=4, kernel_size=3, padding='VALID')
+    with pytest.raises(AssertionError):
+        npm.layers.Conv2D(channels=4, kernel_size=3, strides=(2, 2))
+
+
+def test_trainer_conv_stack(npm, capsys):
+    """reference train_test.py:51-81 (k = 1,3,5,3,1; c = 16,32,64,32,16 on [16,32,32,16], SGD 1e-6),
+    3 steps, losses and final filters against the oracle run on the same seeded parameters."""
+    import re
+    np.random.seed(0)
+    ks, cs = [1, 3, 5, 3, 1], [16, 32, 64, 32, 16]
+    stack = [npm.layers.Conv2D(channels=c, kernel_size=k, name=f'layer_{i}') for i, (c, k) in enumerate(zip(cs, ks))]
+    x = np.random.uniform(-1.0, 1.0, size=[16, 32, 32, 16]).astype(np.float32)
+    t = np.random.uniform(0.0, 1.0, size=[16, 32, 32, 16]).astype(np.float32)
+    state = np.random.get_state()
+    trainer = npm.train.Trainer(stack)
+    trainer.train(inputs=x, targets=t, steps=3, optimizer_=npm.optimizer.SGDOptimizer(1e-6))
+    losses = [float(v) for v in re.findall(r'Loss:\s+([0-9.eE+-]+)', capsys.readouterr().out)]
+    # oracle: same draws (w then b per layer at first forward), same loop
+    np.random.set_state(state)
+    params = []
+    cin = 16
+    for c, k in zip(cs, ks):
+        params.append([O.random_init([k, k, cin, c]).astype(np.float64), O.random_init([c]).astype(np.float64)])
+        cin = c
+    want = []
+    for _ in range(3):
+        acts, pres = [x.astype(np.float64)], []
+        for wgt, b in params:
+            y, pre = O.conv_layer_fwd(acts[-1], wgt, b)
+            acts.append(y)
+            pres.append(pre)
+        want.append(O.mse_fwd(acts[-1], t))
+        dy = O.mse_bwd(acts[-1], t)
+        for i in reversed(range(5)):
+            dy, dw, db = O.conv_layer_bwd(acts[i], params[i][0], pres[i], dy)
+            params[i][0] = params[i][0] - 1e-6 * dw
+            params[i][1] = params[i][1] - 1e-6 * db
+    np.testing.assert_allclose(losses, want, rtol=2e-5)
+    for i, layer in enumerate(stack):
+        assert_close(layer.w, params[i][0], tol=1e-5, what=f'w{i}')
