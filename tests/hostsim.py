@@ -1,0 +1,246 @@
+"""TEST INFRASTRUCTURE ONLY -- a host-memory simulator of the libnpm_hip.so C ABI.
+
+It lets the CPU test-suite exercise the *host-side* logic of the product (Layer protocol,
+DeviceArray/optimizer contract, gradient bucketing, the data-parallel exchange over gloo)
+in a container without a GPU.  "Device pointers" are addresses of NumPy buffers; every
+entry point is restated with NumPy / the oracle.  The product never loads this: tests
+install it explicitly with ``hostsim.install()`` (which sets ``np_modeling_amd._C._LIB``).
+Numerical parity of the real kernels is established on the GPU (tests marked ``gpu``).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from oracle import np_oracle as O
+
+
+def _deref(arg):
+    return arg._obj if hasattr(arg, '_obj') else arg
+
+
+def _addr(p):
+    if p is None:
+        return 0
+    if isinstance(p, int):
+        return p
+    v = getattr(p, 'value', None)
+    return int(v) if v else 0
+
+
+def _vec(ptr, n):
+    n = int(n)
+    if n == 0:
+        return np.zeros(0, dtype=np.float32)
+    return np.ctypeslib.as_array((C.c_float * n).from_address(_addr(ptr)))
+
+
+def _mat(ptr, rows, cols, ld):
+    rows, cols, ld = int(rows), int(cols), int(ld)
+    if rows == 0 or cols == 0:
+        return np.zeros((rows, cols), dtype=np.float32)
+    flat = _vec(ptr, (rows - 1) * ld + cols)
+    return np.lib.stride_tricks.as_strided(flat, shape=(rows, cols), strides=(4 * ld, 4))
+
+
+class HostSim:
+    def __init__(self):
+        self._blocks = {}
+        self._err = b''
+        self.calls = []
+
+    # ---- runtime ---------------------------------------------------------------------
+    def npm_abi_version(self):
+        return 1
+
+    def npm_last_error(self):
+        return self._err
+
+    def npm_init(self, device):
+        return 0
+
+    def npm_shutdown(self):
+        return 0
+
+    def npm_sync(self):
+        return 0
+
+    def npm_stream(self):
+        return 0
+
+    def npm_malloc(self, out, nbytes):
+        buf = np.empty(max(int(nbytes), 4) // 4 + 4, dtype=np.float32)
+        buf.fill(np.nan)                                   # poison: catches reads of unwritten memory
+        addr = buf.ctypes.data
+        addr_aligned = (addr + 15) // 16 * 16
+        self._blocks[addr_aligned] = buf
+        _deref(out).value = addr_aligned
+        return 0
+
+    def npm_free(self, ptr):
+        self._blocks.pop(_addr(ptr), None)
+        return 0
+
+    def npm_pool_stats(self, a, b):
+        _deref(a).value = sum(v.nbytes for v in self._blocks.values())
+        _deref(b).value = _deref(a).value
+        return 0
+
+    def npm_pool_trim(self):
+        return 0
+
+    def npm_h2d(self, dst, src, nbytes):
+        C.memmove(_addr(dst), _addr(src), int(nbytes))
+        return 0
+
+    npm_d2h = npm_h2d
+    npm_d2d = npm_h2d
+
+    def npm_fill_f32(self, dst, value, n):
+        _vec(dst, n)[:] = value
+        return 0
+
+    def npm_event_create(self, out):
+        _deref(out).value = 1
+        return 0
+
+    def npm_event_destroy(self, ev):
+        return 0
+
+    npm_event_record = npm_event_sync = npm_event_destroy
+
+    def npm_event_elapsed_ms(self, a, b, out):
+        _deref(out).value = 0.0
+        return 0
+
+    # ---- GEMM ----------------------------------------------------------------------------
+    def npm_sgemm(self, gref):
+        g = _deref(gref)
+        self.calls.append('npm_sgemm')
+        for z0 in range(g.batch0):
+            for z1 in range(g.batch1):
+                oa = 4 * (z0 * g.stride_a0 + z1 * g.stride_a1)
+                ob = 4 * (z0 * g.stride_b0 + z1 * g.stride_b1)
+                oc = 4 * (z0 * g.stride_c0 + z1 * g.stride_c1)
+                a = _mat(g.a + oa, g.k, g.m, g.lda).T if g.trans_a else _mat(g.a + oa, g.m, g.k, g.lda)
+                b = _mat(g.b + ob, g.n, g.k, g.ldb).T if g.trans_b else _mat(g.b + ob, g.k, g.n, g.ldb)
+                v = np.float64(g.alpha) * (a.astype(np.float64) @ b.astype(np.float64))
+                if g.epilogue & 1:
+                    v = v + _vec(g.bias, g.n).astype(np.float64)
+                if g.epilogue & 2:
+                    v = v + _mat(g.residual + oc, g.m, g.n, g.ldr).astype(np.float64)
+                if g.epilogue & 4:
+                    _mat(g.aux + oc, g.m, g.n, g.ldaux)[:] = v
+                    v = np.maximum(v, 0.0)
+                if g.epilogue & 8:
+                    v = np.where(_mat(g.aux + oc, g.m, g.n, g.ldaux) >= 0, v, 0.0)
+                if g.epilogue & 16:
+                    v = np.maximum(v, 0.0)
+                _mat(g.c + oc, g.m, g.n, g.ldc)[:] = v
+        return 0
+
+    # ---- elementwise ------------------------------------------------------------------------
+    def npm_relu_fwd(self, x, y, n):
+        _vec(y, n)[:] = np.maximum(_vec(x, n), 0)
+        return 0
+
+    def npm_relu_bwd(self, x, dy, dx, n):
+        _vec(dx, n)[:] = np.where(_vec(x, n) >= 0, _vec(dy, n), 0)
+        return 0
+
+    def npm_add(self, a, b, out, n):
+        _vec(out, n)[:] = _vec(a, n) + _vec(b, n)
+        return 0
+
+    def npm_add3(self, a, b, c, out, n):
+        _vec(out, n)[:] = _vec(a, n) + _vec(b, n) + _vec(c, n)
+        return 0
+
+    def npm_axpy(self, y, x, alpha, n):
+        _vec(y, n)[:] = _vec(y, n) + np.float32(alpha) * _vec(x, n)
+        return 0
+
+    def npm_scale(self, x, y, alpha, n):
+        _vec(y, n)[:] = np.float32(alpha) * _vec(x, n)
+        return 0
+
+    def npm_colsum(self, x, out, rows, cols, ld):
+        _vec(out, cols)[:] = _mat(x, rows, cols, ld).astype(np.float64).sum(axis=0)
+        return 0
+
+    # ---- row kernels ---------------------------------------------------------------------------
+    def npm_softmax_fwd(self, x, y, rows, n, scale):
+        _mat(y, rows, n, n)[:] = O.softmax_fwd(np.float64(scale) * _mat(x, rows, n, n).astype(np.float64))
+        return 0
+
+    def npm_softmax_bwd(self, y, dy, dx, rows, n, scale):
+        _mat(dx, rows, n, n)[:] = scale * O.softmax_bwd(_mat(y, rows, n, n), _mat(dy, rows, n, n))
+        return 0
+
+    def npm_layernorm_fwd(self, x, gamma, beta, eps, rows, d, z, mean, rstd):
+        xv = _mat(x, rows, d, d).astype(np.float64)
+        out, (mu, var, _) = O.layernorm_fwd(xv, _vec(gamma, d).astype(np.float64), _vec(beta, d).astype(np.float64), eps)
+        _mat(z, rows, d, d)[:] = out
+        _vec(mean, rows)[:] = mu[:, 0]
+        _vec(rstd, rows)[:] = 1.0 / np.sqrt(var[:, 0] + eps)
+        return 0
+
+    def npm_layernorm_bwd(self, dz, x, mean, rstd, gamma, residual, rows, d, dx, dgamma, dbeta):
+        xv = _mat(x, rows, d, d).astype(np.float64)
+        mu = _vec(mean, rows).astype(np.float64)[:, None]
+        rs = _vec(rstd, rows).astype(np.float64)[:, None]
+        yhat = (xv - mu) * rs
+        dzv = _mat(dz, rows, d, d).astype(np.float64)
+        g = dzv * _vec(gamma, d).astype(np.float64)
+        out = rs * (g - g.mean(axis=1, keepdims=True) - yhat * (g * yhat).mean(axis=1, keepdims=True))
+        if _addr(residual):
+            out = out + _mat(residual, rows, d, d)
+        dg, db = (dzv * yhat).sum(axis=0), dzv.sum(axis=0)
+        _mat(dx, rows, d, d)[:] = out
+        _vec(dgamma, d)[:] = dg
+        _vec(dbeta, d)[:] = db
+        return 0
+
+    # ---- conv -----------------------------------------------------------------------------------
+    def npm_conv2d_fwd(self, cref):
+        c = _deref(cref)
+        x = _vec(c.x, c.n * c.h * c.w * c.c_in).reshape(c.n, c.h, c.w, c.c_in)
+        f = _vec(c.filt, c.ksize * c.ksize * c.c_in * c.c_out).reshape(c.ksize, c.ksize, c.c_in, c.c_out)
+        v = O.conv2d_fwd(x, f)
+        if c.bias:
+            v = v + _vec(c.bias, c.c_out)
+        if c.relu:
+            if c.pre:
+                _vec(c.pre, v.size)[:] = v.ravel()
+            v = np.maximum(v, 0)
+        _vec(c.y, v.size)[:] = v.ravel()
+        return 0
+
+    def npm_conv2d_bwd_x(self, dy, filt, dx, n, h, w, c0, c1, k):
+        g = _vec(dy, n * h * w * c1).reshape(n, h, w, c1)
+        f = _vec(filt, k * k * c0 * c1).reshape(k, k, c0, c1)
+        _vec(dx, n * h * w * c0)[:] = O.conv2d_grad_x(g, f).ravel()
+        return 0
+
+    def npm_conv2d_bwd_w(self, dy, x, dw, n, h, w, c0, c1, k):
+        g = _vec(dy, n * h * w * c1).reshape(n, h, w, c1)
+        xv = _vec(x, n * h * w * c0).reshape(n, h, w, c0)
+        _vec(dw, k * k * c0 * c1)[:] = O.conv2d_grad_w(g, xv, k).ravel()
+        return 0
+
+
+def install():
+    """Install a fresh simulator as the product's library handle; returns it."""
+    from np_modeling_amd import _C
+    sim = HostSim()
+    _C._LIB = sim
+    _C._DEVICE = 0
+    return sim
+
+
+def uninstall():
+    from np_modeling_amd import _C
+    _C._LIB = None
+    _C._DEVICE = None

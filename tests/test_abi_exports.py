@@ -1,0 +1,116 @@
+"""CPU: the C-ABI libraries load and export every symbol the headers declare; the ctypes
+binding declares a prototype for each; the product refuses to run without a GPU."""
+
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared(header):
+    text = open(os.path.join(ROOT, 'include', header)).read()
+    text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
+    return sorted(set(re.findall(r'\b(npm_\w+)\s*\(', text)))
+
+
+@pytest.fixture(scope='module')
+def built():
+    import __graft_entry__ as entry
+    from np_modeling_amd import _C
+    if not (os.path.exists(_C.LIB_PATH) and os.path.exists(_C.RCCL_LIB_PATH)):
+        entry.build()
+    return _C
+
+
+def test_every_declared_symbol_is_exported_and_bound(built):
+    _C = built
+    names = declared('npm_hip.h')
+    assert len(names) >= 35
+    lib = ctypes.CDLL(_C.LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), f'{name} declared in include/npm_hip.h but not exported'
+        assert name in _C.SIGNATURES or name in _C._SPECIAL, f'{name} has no ctypes prototype in _C.py'
+    assert sorted(list(_C.SIGNATURES) + list(_C._SPECIAL)) == names
+
+
+def test_comm_library_exports(built):
+    _C = built
+    names = declared('npm_comm.h')
+    lib = ctypes.CDLL(_C.RCCL_LIB_PATH)
+    for name in names:
+        assert hasattr(lib, name), name
+    assert sorted(list(_C.COMM_SIGNATURES) + list(_C._COMM_SPECIAL)) == names
+
+
+def test_struct_layouts_match_header(built):
+    """npm_gemm / npm_conv2d: field order of the ctypes mirror equals the C declaration."""
+    _C = built
+    text = open(os.path.join(ROOT, 'include', 'npm_hip.h')).read()
+
+    def c_fields(struct):
+        body = re.search(r'typedef struct %s \{(.*?)\} %s;' % (struct, struct), text, flags=re.S).group(1)
+        body = re.sub(r'/\*.*?\*/', '', body, flags=re.S)
+        out = []
+        for decl in body.split(';'):
+            decl = decl.strip()
+            if not decl:
+                continue
+            decl = re.sub(r'^(const\s+)?(float|int32_t|int64_t)\s*\*?', '', decl)
+            out += [n.strip().lstrip('*') for n in decl.split(',')]
+        return out
+
+    assert c_fields('npm_gemm') == [f[0] for f in _C.npm_gemm._fields_]
+    assert c_fields('npm_conv2d') == [f[0] for f in _C.npm_conv2d._fields_]
+    # sizes and a few offsets as a C compiler sees the header (plain C: the header is C-clean)
+    import subprocess
+    import tempfile
+    prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "npm_hip.h"\n#include "npm_comm.h"\n'
+            'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(npm_gemm), offsetof(npm_gemm, alpha), '
+            'offsetof(npm_gemm, split_k), sizeof(npm_conv2d), offsetof(npm_conv2d, relu));return 0;}\n')
+    with tempfile.TemporaryDirectory() as tmp:
+        src = os.path.join(tmp, 'abi.c')
+        open(src, 'w').write(prog)
+        exe = os.path.join(tmp, 'abi')
+        subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), src, '-o', exe], check=True)
+        got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
+    want = [ctypes.sizeof(_C.npm_gemm), _C.npm_gemm.alpha.offset, _C.npm_gemm.split_k.offset,
+            ctypes.sizeof(_C.npm_conv2d), _C.npm_conv2d.relu.offset]
+    assert got == want
+
+
+def test_abi_version_and_no_device_behaviour(built):
+    _C = built
+    lib = _C.load_library()
+    assert lib.npm_abi_version() == 1
+    count = ctypes.c_int(-1)
+    lib.npm_device_count(ctypes.byref(count))
+    if count.value > 0:
+        pytest.skip('a GPU is present; the no-device path is checked in the build container')
+    # no compute without a GPU: every entry point reports NOT_INITIALIZED, init reports NO_DEVICE
+    assert lib.npm_init(0) == 10004
+    assert b'no HIP device' in lib.npm_last_error()
+    assert lib.npm_sync() == 10001
+    p = ctypes.c_void_p()
+    assert lib.npm_malloc(ctypes.byref(p), 1024) == 10001
+    assert lib.npm_sgemm(ctypes.byref(_C.npm_gemm())) == 10001
+
+
+def test_product_fails_loudly_without_gpu(built):
+    _C = built
+    count = ctypes.c_int(0)
+    _C.load_library().npm_device_count(ctypes.byref(count))
+    if count.value > 0:
+        pytest.skip('a GPU is present')
+    import numpy as np
+    import np_modeling_amd as npm
+    assert _C._LIB is None or not hasattr(_C._LIB, 'calls')      # no simulator leaked into this test
+    saved = (_C._LIB, _C._DEVICE)
+    _C._LIB, _C._DEVICE = None, None
+    try:
+        with pytest.raises(_C.NpmError, match='no CPU fallback'):
+            npm.layers.Dense(4)(np.ones((2, 3), dtype=np.float32))
+    finally:
+        _C._LIB, _C._DEVICE = saved

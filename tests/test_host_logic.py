@@ -1,0 +1,210 @@
+"""CPU: host-side logic of the product on the host simulator of the C ABI (tests/hostsim.py):
+Layer protocol, weight layouts / GEMM descriptors against the reference's golden outputs,
+gradient bucketing, and the data-parallel exchange over gloo with world_size 2.
+
+The kernels themselves are validated on the GPU (tests marked ``gpu``); here every kernel is
+the simulator's NumPy restatement, so a failure points at the Python host layer."""
+
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import hostsim
+from conftest import assert_close, load_golden
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture
+def npm():
+    import np_modeling_amd
+    from np_modeling_amd import parallel
+    hostsim.install()
+    parallel.set_communicator(None)
+    yield np_modeling_amd
+    parallel.set_communicator(None)
+    hostsim.uninstall()
+
+
+def rand(shape):
+    return np.random.normal(size=shape).astype(np.float32)
+
+
+def test_dense_golden_on_simulator(npm):
+    g = load_golden('dense')
+    np.random.seed(0)
+    layer = npm.layers.Dense(units=16)
+    x = rand([64, 32])
+    y = layer(x)
+    w, b = layer.linear.w, layer.linear.b
+    np.testing.assert_array_equal(np.asarray(w), g['w0'])
+    assert_close(y, g['y'], tol=1e-6)
+    dx = layer(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=1e-6)
+    assert_close(w, g['w1'], tol=1e-6)
+    assert_close(b, g['b1'], tol=1e-6)
+
+
+@pytest.mark.parametrize('name', ['mha_self', 'mha_cross'])
+def test_mha_descriptors_on_simulator(npm, name):
+    """Head-strided operand descriptors and weight layouts of attentions.py against the reference."""
+    g = load_golden(name)
+    layer = npm.layers.MultiHeadAttention(num_heads=int(g['heads']))
+    kv = g.get('kv')
+    args = (g['query'],) if kv is None else (g['query'], kv)
+    layer(*args)
+    names = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+    for n in names:
+        setattr(layer, '_' + n, g[n + '0'])
+    assert_close(layer(*args), g['out'], tol=1e-5)
+    dq, dk, dv = layer(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dq, g['dquery'], tol=1e-5)
+    assert_close(dk, g['dkey'], tol=1e-5)
+    assert_close(dv, g['dvalue'], tol=1e-5)
+    for n in names:
+        assert_close(getattr(layer, '_' + n), g[n + '1'], tol=1e-5, what=n)
+
+
+@pytest.mark.parametrize('name', ['encoder_prenorm', 'encoder_postnorm'])
+def test_encoder_composition_on_simulator(npm, name):
+    g = load_golden(name)
+    np.random.seed(0)
+    enc = npm.layers.TransformerEncoder(num_heads=int(g['heads']), hidden_units=int(g['hidden']),
+                                        norm_first=bool(g['norm_first']))
+    out = enc(rand(g['qkv'].shape))
+    assert_close(out, g['out'], tol=1e-5)
+    dx = enc(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=1e-5)
+    assert_close(enc._dense2.w, g['d2_w__1'], tol=1e-5)
+    assert_close(enc._self_attention._wq, g['att_wq__1'], tol=1e-5)
+    assert_close(enc._norm1._gamma, g['n1_gamma__1'], tol=1e-5)
+
+
+def test_conv_layer_on_simulator(npm):
+    g = load_golden('conv_k3')
+    np.random.seed(0)
+    layer = npm.layers.Conv2D(channels=12, kernel_size=3)
+    y = layer(rand([3, 9, 7, 8]))
+    assert_close(y, g['y'], tol=1e-6)
+    dx = layer(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=1e-6)
+    assert_close(layer.w, g['w1'], tol=1e-6)
+
+
+def test_device_array_contract(npm):
+    import copy
+    D = npm.device
+    a = D.from_host(np.arange(6, dtype=np.float32).reshape(2, 3))
+    alias = a
+    a -= 0.5 * D.from_host(np.ones((2, 3), dtype=np.float32))          # lr * grad stays symbolic -> one axpy
+    assert a is alias
+    np.testing.assert_array_equal(np.asarray(alias), np.arange(6).reshape(2, 3) - 0.5)
+    a -= np.full((2, 3), 0.5)                                            # host operand (Adam's update)
+    np.testing.assert_array_equal(np.asarray(a), np.arange(6).reshape(2, 3) - 1.0)
+    b = copy.deepcopy(a)
+    b += 1.0
+    assert not np.array_equal(np.asarray(a), np.asarray(b))
+    assert a.reshape(-1).shape == (6,) and a.reshape(3, -1).shape == (3, 2)
+    with pytest.raises(ValueError):
+        a.reshape(4, 2)
+    assert np.asarray(a, dtype=np.float64).dtype == np.float64
+    assert (np.ones((2, 3)) + a).shape == (2, 3)                         # ndarray op DeviceArray -> host math
+    assert isinstance(2.0 * a, D.Scaled) and np.allclose(np.asarray(2.0 * a), 2 * np.asarray(a))
+    v = a.flat_view(2, [2, 2])
+    v -= D.from_host(np.ones((2, 2), dtype=np.float32))
+    assert np.asarray(a).ravel()[2] == 0.0                               # views alias their base
+
+
+def test_grad_scope_bucket_and_deferred_updates(npm):
+    """world_size 2 with a recording transport: one flat bucket, 16-byte aligned slices, every
+    element exchanged exactly once, updates applied only after the exchange."""
+    from np_modeling_amd import parallel
+    D = npm.device
+    events = []
+
+    class Recorder(parallel.Communicator):
+        rank, world_size = 0, 2
+
+        def allreduce_async(self, flat, op):
+            events.append(('allreduce', flat.ptr, flat.size, op))
+
+        def wait(self):
+            events.append(('wait',))
+
+    class Opt:
+        def update(self, obj, attribute, gradient):
+            events.append(('update', attribute))
+
+    parallel.set_communicator(Recorder())
+    with parallel.grad_scope(64) as scope:
+        g1 = scope.take([3])
+        g2 = scope.take([2, 5])
+        assert (g2.ptr - g1.ptr) % 16 == 0 and g2.ptr - g1.ptr == 16
+        scope.defer(Opt(), None, '_a', g1)
+        scope.flush()
+        with parallel.grad_scope(8) as inner:                 # nested scope delegates to the root bucket
+            g3 = inner.take([4])
+            inner.defer(Opt(), None, '_b', g3)
+        g_big = scope.take([1000])                             # does not fit: exchanged on its own
+        scope.defer(Opt(), None, '_c', g_big)
+        assert [e[0] for e in events] == ['allreduce']         # nothing applied yet
+    kinds = [e[0] for e in events]
+    assert kinds == ['allreduce', 'allreduce', 'allreduce', 'wait', 'update', 'update', 'update']
+    first, second, third = events[0], events[1], events[2]
+    assert first[1] == g1.ptr and first[2] == 14                # [0, 3) pad to 4, [4, 14)
+    assert second[1] == g1.ptr + 4 * 14 and second[2] == 6      # [14, 16) pad, [16, 20)
+    assert third[2] == 1000
+    assert all(e[3] == parallel.AVG for e in events[:3])
+    # world_size 1: no bucket, no exchange, updates still deferred to scope exit
+    events.clear()
+    parallel.set_communicator(None)
+    with parallel.grad_scope(64) as scope:
+        scope.defer(Opt(), None, '_a', scope.take([3]))
+        assert events == []
+    assert events == [('update', '_a')]
+
+
+def test_shard_helper(npm):
+    from np_modeling_amd import parallel
+
+    class Two(parallel.Communicator):
+        rank, world_size = 1, 2
+
+    parallel.set_communicator(Two())
+    x = np.arange(24).reshape(4, 6)
+    np.testing.assert_array_equal(parallel.shard(x), x[2:])
+    with pytest.raises(AssertionError):
+        parallel.shard(np.zeros((3, 2)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def test_data_parallel_equivalence_gloo():
+    """Two processes, gloo: batch-sharded training of an MLP stack and of pre-/post-norm encoders
+    ends with the same parameters as one process on the whole batch."""
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   OMP_NUM_THREADS='2', OPENBLAS_NUM_THREADS='2')
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py')], env=env,
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=240)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
+    assert 'encoder_post' in outs[0]
