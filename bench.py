@@ -144,7 +144,7 @@ def main():
             enc(qkv)                                     # (step 0's forward ran above, before bind)
         enc(dy, backprop=True, optimizer_=sgd)
     D.synchronize()
-    if world > 1:
+    if comm.active:
         comm.barrier()
 
     timer = None if args.no_kernel_timer else D.KernelTimer()
@@ -154,12 +154,12 @@ def main():
     for _ in range(args.steps):
         step()
     D.synchronize()
-    if world > 1:
+    if comm.active:
         comm.barrier()
     elapsed = time.perf_counter() - t0
     if timer is not None:
         timer.__exit__(None, None, None)
-    if world > 1:
+    if comm.active:
         elapsed = comm.allreduce_scalar(elapsed, parallel.MAX)
 
     total_samples = args.batch * world * args.steps

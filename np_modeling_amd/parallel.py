@@ -39,6 +39,11 @@ class Communicator:
     rank = 0
     world_size = 1
 
+    @property
+    def active(self) -> bool:
+        """Whether gradients have to be exchanged at all."""
+        return self.world_size > 1
+
     def allreduce_async(self, flat: 'D.DeviceArray', op: int) -> None:
         raise NotImplementedError
 
@@ -60,6 +65,8 @@ class Communicator:
 
 class RcclCommunicator(Communicator):
     """RCCL through libnpm_rccl.so (include/npm_comm.h)."""
+
+    active = True      # also with one rank (NPM_FORCE_RCCL=1): exercises the whole exchange path
 
     def __init__(self, rank: int, world_size: int, unique_id: bytes):
         self._lib = _C.comm_lib()
@@ -125,11 +132,11 @@ def init(reduce: str = 'avg') -> Communicator:
         return _COMM
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if world <= 1:
+    if world <= 1 and os.environ.get('NPM_FORCE_RCCL', '0') != '1':
         _COMM = Communicator()
         return _COMM
     _C.lib()                                             # bind this process to cuda:LOCAL_RANK first
-    uid = _exchange_unique_id(rank, world)
+    uid = _exchange_unique_id(rank, world) if 'MASTER_PORT' in os.environ else RcclCommunicator.new_unique_id()
     _COMM = RcclCommunicator(rank, world, uid)
     return _COMM
 
@@ -198,7 +205,7 @@ class GradScope:
         self._outer = GradScope._active
         if self._outer is None:
             GradScope._active = self
-            if world_size() > 1 and self._hint > 0:
+            if communicator().active and self._hint > 0:
                 self._bucket = D.empty([self._hint])
         return self
 
@@ -224,7 +231,7 @@ class GradScope:
                 root._offset = start + n
                 return root._bucket.flat_view(start, shape)
         g = D.empty(shape)
-        if world_size() > 1:
+        if communicator().active:
             root._loose.append(g)
         return g
 
@@ -235,7 +242,7 @@ class GradScope:
         """Start exchanging every gradient produced so far (asynchronous)."""
         root = self.root
         comm = communicator()
-        if comm.world_size <= 1:
+        if not comm.active:
             return
         if root._bucket is not None and root._offset > root._flushed:
             begin = root._flushed
@@ -247,7 +254,7 @@ class GradScope:
 
     def _finish(self) -> None:
         comm = communicator()
-        if comm.world_size > 1:
+        if comm.active:
             self.flush()
             comm.wait()
         updates, self._updates = self._updates, []

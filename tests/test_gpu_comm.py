@@ -1,0 +1,54 @@
+"""GPU: the RCCL shim (libnpm_rccl.so) with a one-rank communicator -- unique id, init, stream
+ordering of an in-place all-reduce against the compute stream, broadcast, barrier, host scalar
+reduction -- and a full encoder step with the exchange path active (flat bucket + deferred
+updates) giving the same parameters as the plain single-GPU path."""
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def comm():
+    import np_modeling_amd  # noqa: F401
+    from np_modeling_amd import _C, parallel
+    _C.lib()
+    c = parallel.RcclCommunicator(0, 1, parallel.RcclCommunicator.new_unique_id())
+    yield c
+    parallel.set_communicator(None)
+    c.close()
+
+
+def test_rccl_single_rank_collectives(comm):
+    from np_modeling_amd import device as D, parallel
+    x = np.random.default_rng(0).standard_normal(1 << 20).astype(np.float32)
+    d = D.from_host(x)
+    d *= 2.0                                        # compute-stream work the collective must wait for
+    comm.allreduce_async(d, parallel.AVG)
+    comm.wait()
+    d += 1.0                                        # compute-stream work that must wait for the collective
+    np.testing.assert_array_equal(d.numpy(), x * 2 + 1)
+    comm.allreduce_async(d.flat_view(5, [1000]), parallel.SUM)
+    comm.broadcast(d)
+    comm.barrier()
+    assert comm.allreduce_scalar(3.5, parallel.MAX) == 3.5
+    np.testing.assert_array_equal(d.numpy(), x * 2 + 1)
+
+
+def test_encoder_step_with_exchange_path_active(comm):
+    import np_modeling_amd as npm
+    from np_modeling_amd import parallel
+
+    def run(active):
+        parallel.set_communicator(comm if active else None)
+        np.random.seed(0)
+        enc = npm.layers.TransformerEncoder(num_heads=4, hidden_units=64, norm_first=True)
+        x = np.random.normal(size=[4, 16, 32]).astype(np.float32)
+        dy = np.random.normal(size=[4, 16, 32]).astype(np.float32)
+        enc(x)
+        dx = np.asarray(enc(dy, backprop=True, learning_rate=0.01))
+        return dx, np.asarray(enc._dense2.w), np.asarray(enc._self_attention._wq), np.asarray(enc._norm1._beta)
+
+    for a, b in zip(run(False), run(True)):
+        np.testing.assert_array_equal(a, b)
