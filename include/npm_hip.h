@@ -97,6 +97,10 @@ typedef struct npm_gemm {
 
 int npm_sgemm(const npm_gemm *g);
 
+/* Tuning knobs (A/B experiments in one process; defaults are the shipped configuration). */
+enum { NPM_TUNE_GEMM_PIPELINE = 0, NPM_TUNE_GEMM_STAGGER = 1, NPM_TUNE_GEMM_GROUP_M = 2 };
+int npm_set_tuning(int knob, int value);
+
 /* ---- elementwise ---------------------------------------------------------- */
 int npm_relu_fwd(const float *x, float *y, size_t n);                      /* activations.py:15 */
 int npm_relu_bwd(const float *x_pre, const float *dy, float *dx, size_t n);/* activations.py:19 (x >= 0) */

@@ -73,6 +73,7 @@ SIGNATURES = {
     'npm_event_sync': [_P],
     'npm_event_elapsed_ms': [_P, _P, C.POINTER(_F)],
     'npm_sgemm': [C.POINTER(npm_gemm)],
+    'npm_set_tuning': [C.c_int, C.c_int],
     'npm_relu_fwd': [_P, _P, _SZ],
     'npm_relu_bwd': [_P, _P, _P, _SZ],
     'npm_add': [_P, _P, _P, _SZ],
@@ -153,6 +154,9 @@ def lib():
             raise NpmError(f'npm_init({device}) failed with code {rc}: '
                            f'{msg.decode() if msg else "?"} -- an MI355X is required, there is no CPU fallback')
         _DEVICE = device
+        for item in filter(None, os.environ.get('NPM_TUNE', '').split(',')):     # e.g. NPM_TUNE=0=2 (A/B experiments)
+            knob, value = item.split('=')
+            check(_LIB.npm_set_tuning(int(knob), int(value)), 'npm_set_tuning')
     return _LIB
 
 

@@ -38,16 +38,24 @@ struct GemmArgs {
     int batch1;
     int tiles_m, tiles_n, splits, k_per_split;
     int group_m;
+    int stagger;     // 0 = off, else blocks per residency generation (tuning knob)
+    int ablate;      // timing-only experiments: 1 skip global loads, 2 skip LDS stores, 4 skip barriers
     long slab;       // split-K: batch * M * N
     Epilogue e;
 };
 
-template <bool A_KMAJ, bool B_KMAJ, bool VEC>
+int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline where eligible
+int g_stagger = 0;
+int g_group_m = 8;
+int g_ablate = 0;
+
+// PIPE 0: one LDS buffer, two barriers per K tile (36 KB LDS, 3 blocks/CU).
+// PIPE 1: two LDS buffers, ONE barrier per K tile: tile t+1 is written into the other buffer
+//         between the two halves of tile t's MFMAs (72 KB LDS, 2 blocks/CU).
+template <bool A_KMAJ, bool B_KMAJ, bool VEC, int PIPE>
 __global__ void __launch_bounds__(NTHREADS)
 sgemm_mfma_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * TILE_FLOATS];
-    float *sA = smem;
-    float *sB = smem + TILE_FLOATS;
+    __shared__ __attribute__((aligned(16))) float smem[(PIPE ? 4 : 2) * TILE_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -73,14 +81,21 @@ sgemm_mfma_kernel(const GemmArgs p) {
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nkt = (kend - kbeg + BK - 1) / BK;
 
+    if (p.stagger && blockIdx.x < 3 * 256) {
+        // de-phase the first generation of blocks that share a CU: identical blocks started together
+        // reach their barriers and LDS refills together and leave the matrix pipe idle meanwhile
+        const int slot = blockIdx.x / 256;
+        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);     // 1024 cycles each
+    }
+
     f32x16 acc[2][2];
     zero_acc(acc);
 
     float4 ra[4], rb[4];
     load_tile<A_KMAJ, VEC>(A, p.lda, m0, p.M, kbeg, kend, tid, ra);
     load_tile<B_KMAJ, VEC>(B, p.ldb, n0, p.N, kbeg, kend, tid, rb);
-    store_tile<A_KMAJ>(sA, tid, ra);
-    store_tile<B_KMAJ>(sB, tid, rb);
+    store_tile<A_KMAJ>(smem, tid, ra);
+    store_tile<B_KMAJ>(smem + TILE_FLOATS, tid, rb);
     __syncthreads();
 
     const int arow = wm * 64 + l32;
@@ -88,18 +103,168 @@ sgemm_mfma_kernel(const GemmArgs p) {
 
     for (int kt = 0; kt < nkt; ++kt) {
         const bool more = kt + 1 < nkt;
-        if (more) {   // next tile's global loads fly under this tile's MFMAs
+        if (more && !(p.ablate & 1)) {   // next tile's global loads fly under this tile's MFMAs
             const int k0 = kbeg + (kt + 1) * BK;
             load_tile<A_KMAJ, VEC>(A, p.lda, m0, p.M, k0, kend, tid, ra);
             load_tile<B_KMAJ, VEC>(B, p.ldb, n0, p.N, k0, kend, tid, rb);
         }
-        mma_tile<A_KMAJ, B_KMAJ>(sA, sB, arow, brow, half, acc);
-        __syncthreads();
-        if (more) {
-            store_tile<A_KMAJ>(sA, tid, ra);
-            store_tile<B_KMAJ>(sB, tid, rb);
+        if (PIPE == 0) {
+            mma_tile<A_KMAJ, B_KMAJ>(smem, smem + TILE_FLOATS, arow, brow, half, acc);
+            if (!(p.ablate & 4)) __syncthreads();
+            if (more && !(p.ablate & 2)) {
+                store_tile<A_KMAJ>(smem, tid, ra);
+                store_tile<B_KMAJ>(smem + TILE_FLOATS, tid, rb);
+            }
+            if (!(p.ablate & 4)) __syncthreads();
+        } else {
+            const float *cur = smem + (kt & 1) * 2 * TILE_FLOATS;
+            float *nxt = smem + ((kt + 1) & 1) * 2 * TILE_FLOATS;
+            mma_groups<A_KMAJ, B_KMAJ, 0, 2>(cur, cur + TILE_FLOATS, arow, brow, half, acc);
+            if (more) {   // every wave passed the barrier that ended tile kt-1: nobody reads `nxt` any more
+                store_tile<A_KMAJ>(nxt, tid, ra);
+                store_tile<B_KMAJ>(nxt + TILE_FLOATS, tid, rb);
+            }
+            mma_groups<A_KMAJ, B_KMAJ, 2, 4>(cur, cur + TILE_FLOATS, arow, brow, half, acc);
+            __syncthreads();
         }
+    }
+
+    Epilogue e = p.e;
+    if (p.splits > 1) {
+        e.ws += (long)split * p.slab + (long)z * p.M * p.N;
+        write_tile(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
+        return;
+    }
+    const long coff = z0 * p.sC0 + z1 * p.sC1;
+    e.C += coff;
+    if (e.R) e.R += coff;
+    if (e.aux) e.aux += coff;
+    write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+}
+
+// ------------------------------------------------------------------------------------------
+// PIPE 2: operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds): no staging
+// VGPRs, no ds_write pass, no per-load bounds branches (the buffer descriptor's range check
+// returns 0 beyond the operand; rows beyond M / N only feed outputs that are never stored).
+// K step 16, two LDS stages of 16 KB, ONE barrier per K tile; 128 registers -> 4 blocks per CU.
+// The LDS image of a DMA is lane-linear, so the bank-conflict swizzle of the K-major tiles
+// ([128 rows][64 B]) is applied to the SOURCE address: LDS chunk c' of row r holds global chunk
+// c' ^ ((r >> 2) & 3); reads apply the same XOR (conflict-free ds_read_b128).
+// Needs 16-byte aligned operands and K (and every split) a multiple of 16.
+// ------------------------------------------------------------------------------------------
+constexpr int GK = 16;                         // K step of the DMA pipeline
+constexpr int G_TILE = BM * GK;                // floats per operand tile (8 KB)
+constexpr int G_STAGE = 2 * G_TILE;            // A + B
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <bool KMAJ>
+__device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
+    // byte offset of this lane's 16-byte chunk for wave-instruction j (0..7) of a tile, relative
+    // to the tile's first row (K-major) / first k row (MN-major), K offset excluded
+    if (KMAJ) {
+        const int row = 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        return (unsigned)(row * ld * 4 + c * 16);
+    } else {
+        const int krow = 2 * j + (lane >> 5);
+        return (unsigned)(krow * ld * 4 + (lane & 31) * 16);
+    }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ float4 read_frag16(const float *__restrict__ s, int row, int g, int half) {
+    if (KMAJ) {
+        const int c = (2 * g + half) ^ ((row >> 2) & 3);
+        return *reinterpret_cast<const float4 *>(s + row * GK + c * 4);
+    } else {
+        const float *p = s + (8 * g + 4 * half) * BM + row;
+        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+    }
+}
+
+template <bool A_KMAJ, bool B_KMAJ>
+__global__ void __launch_bounds__(NTHREADS, 4)
+sgemm_glds_kernel(const GemmArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l32 = lane & 31, half = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int t = logical % tiles;
+    const int rest = logical / tiles;
+    const int split = rest % p.splits;
+    const int z = rest / p.splits;
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
+
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg) / GK;
+
+    // Buffer descriptors rebased to this block's panel; num_records = bytes up to the end of the
+    // operand's valid extent, so every access beyond the matrix reads 0 instead of faulting.
+    const long a_batch = z0 * p.sA0 + z1 * p.sA1, b_batch = z0 * p.sB0 + z1 * p.sB1;
+    const long a_extent = A_KMAJ ? (long)(p.M - 1) * p.lda + p.K : (long)(p.K - 1) * p.lda + p.M;
+    const long b_extent = B_KMAJ ? (long)(p.N - 1) * p.ldb + p.K : (long)(p.K - 1) * p.ldb + p.N;
+    const long a_panel = A_KMAJ ? (long)m0 * p.lda + kbeg : (long)kbeg * p.lda + m0;
+    const long b_panel = B_KMAJ ? (long)n0 * p.ldb + kbeg : (long)kbeg * p.ldb + n0;
+    const long a_left = max(a_extent - a_panel, 0L) * 4, b_left = max(b_extent - b_panel, 0L) * 4;
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.A + a_batch + a_panel), 0,
+                                                         (int)min(a_left, 0xFFFFFFFFL), 0x00020000);
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.B + b_batch + b_panel), 0,
+                                                         (int)min(b_left, 0xFFFFFFFFL), 0x00020000);
+    // each wave issues DMA pieces j = 2*wave, 2*wave+1 of both operand tiles
+    const unsigned va0 = glds_voffset<A_KMAJ>(lane, 2 * wave, p.lda), va1 = glds_voffset<A_KMAJ>(lane, 2 * wave + 1, p.lda);
+    const unsigned vb0 = glds_voffset<B_KMAJ>(lane, 2 * wave, p.ldb), vb1 = glds_voffset<B_KMAJ>(lane, 2 * wave + 1, p.ldb);
+    const unsigned a_kstep = A_KMAJ ? GK * 4u : (unsigned)(GK * p.lda * 4);
+    const unsigned b_kstep = B_KMAJ ? GK * 4u : (unsigned)(GK * p.ldb * 4);
+
+    auto issue = [&](int kt, int stage) {
+        float *sa = smem + stage * G_STAGE + (2 * wave) * 256;        // 1 KiB per piece
+        float *sb = sa + G_TILE;
+        const unsigned ka = kt * a_kstep, kb = kt * b_kstep;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)sa, 16, va0, ka, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(sa + 256), 16, va1, ka, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)sb, 16, vb0, kb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(sb + 256), 16, vb1, kb, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int arow = wm * 64 + l32;
+    const int brow = wn * 64 + l32;
+
+    if (nkt > 0) issue(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        // tile kt has landed (every wave's pieces) and everybody is done reading the other stage
         __syncthreads();
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        const float *sA = smem + (kt & 1) * G_STAGE;
+        const float *sB = sA + G_TILE;
+#pragma unroll
+        for (int g = 0; g < GK / 8; ++g) {
+            const float4 a0 = read_frag16<A_KMAJ>(sA, arow, g, half);
+            const float4 a1 = read_frag16<A_KMAJ>(sA, arow + 32, g, half);
+            const float4 b0 = read_frag16<B_KMAJ>(sB, brow, g, half);
+            const float4 b1 = read_frag16<B_KMAJ>(sB, brow + 32, g, half);
+            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+        }
     }
 
     Epilogue e = p.e;
@@ -119,10 +284,17 @@ inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 template <bool A_KMAJ, bool B_KMAJ>
 void launch(const GemmArgs &a, bool vec, int grid, hipStream_t stream) {
-    if (vec)
-        hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    const bool dma_ok = vec && a.K % GK == 0 && a.k_per_split % GK == 0 &&
+                        (A_KMAJ ? (long)BM * a.lda + a.K : (long)a.k_per_split * a.lda + BM) * 4 < (1L << 31) &&
+                        (B_KMAJ ? (long)BN * a.ldb + a.K : (long)a.k_per_split * a.ldb + BN) * 4 < (1L << 31);
+    if (g_pipe == 2 && dma_ok)
+        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    else if (!vec)
+        hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, false, 0>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    else if (g_pipe == 1)
+        hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, true, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
     else
-        hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+        hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, true, 0>), dim3(grid), dim3(NTHREADS), 0, stream, a);
 }
 
 }  // namespace
@@ -157,6 +329,16 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 
 }  // namespace npm_tile
 
+extern "C" int npm_set_tuning(int knob, int value) {
+    switch (knob) {
+        case NPM_TUNE_GEMM_PIPELINE: g_pipe = value; return NPM_OK;
+        case NPM_TUNE_GEMM_STAGGER: g_stagger = value; return NPM_OK;
+        case NPM_TUNE_GEMM_GROUP_M: g_group_m = value > 0 ? value : 8; return NPM_OK;
+        case 99: g_ablate = value; return NPM_OK;
+        default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
+    }
+}
+
 extern "C" int npm_sgemm(const npm_gemm *g) {
     NPM_REQUIRE_INIT();
     NPM_ARG(g != nullptr);
@@ -190,7 +372,9 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.e.ldr = g->ldr;
     a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) ? g->aux : nullptr;
     a.e.ldaux = g->ldaux;
-    a.group_m = 8;
+    a.group_m = g_group_m;
+    a.stagger = g_stagger;
+    a.ablate = g_ablate;
 
     const long batch = (long)g->batch0 * g->batch1;
     const long tiles = (long)a.tiles_m * a.tiles_n * batch;

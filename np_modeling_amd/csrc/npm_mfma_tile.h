@@ -85,12 +85,12 @@ __device__ __forceinline__ void zero_acc(f32x16 (&acc)[2][2]) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 }
 
-// The 64 MFMAs of one K tile for one wave.
-template <bool A_KMAJ, bool B_KMAJ>
-__device__ __forceinline__ void mma_tile(const float *__restrict__ sA, const float *__restrict__ sB,
-                                         int arow, int brow, int half, f32x16 (&acc)[2][2]) {
+// MFMAs of k-groups [G0, G1) of one K tile for one wave (16 per group).
+template <bool A_KMAJ, bool B_KMAJ, int G0, int G1>
+__device__ __forceinline__ void mma_groups(const float *__restrict__ sA, const float *__restrict__ sB,
+                                           int arow, int brow, int half, f32x16 (&acc)[2][2]) {
 #pragma unroll
-    for (int g = 0; g < BK / 8; ++g) {
+    for (int g = G0; g < G1; ++g) {
         const float4 a0 = read_frag<A_KMAJ>(sA, arow, g, half);
         const float4 a1 = read_frag<A_KMAJ>(sA, arow + 32, g, half);
         const float4 b0 = read_frag<B_KMAJ>(sB, brow, g, half);
@@ -105,6 +105,13 @@ __device__ __forceinline__ void mma_tile(const float *__restrict__ sA, const flo
                 for (int j = 0; j < 2; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
     }
+}
+
+// The 64 MFMAs of one K tile for one wave.
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void mma_tile(const float *__restrict__ sA, const float *__restrict__ sB,
+                                         int arow, int brow, int half, f32x16 (&acc)[2][2]) {
+    mma_groups<A_KMAJ, B_KMAJ, 0, BK / 8>(sA, sB, arow, brow, half, acc);
 }
 
 // C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 half.
