@@ -48,6 +48,7 @@ int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline whe
 int g_stagger = 0;
 int g_group_m = 8;
 int g_ablate = 0;
+int g_buf_epilogue = 1;
 
 // PIPE 0: one LDS buffer, two barriers per K tile (36 KB LDS, 3 blocks/CU).
 // PIPE 1: two LDS buffers, ONE barrier per K tile: tile t+1 is written into the other buffer
@@ -270,14 +271,16 @@ sgemm_glds_kernel(const GemmArgs p) {
     Epilogue e = p.e;
     if (p.splits > 1) {
         e.ws += (long)split * p.slab + (long)z * p.M * p.N;
-        write_tile(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
+        if (e.buf_ok) write_tile_buf(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
+        else write_tile(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
         return;
     }
     const long coff = z0 * p.sC0 + z1 * p.sC1;
     e.C += coff;
     if (e.R) e.R += coff;
     if (e.aux) e.aux += coff;
-    write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+    if (e.buf_ok) write_tile_buf(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+    else write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
 
 inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
@@ -335,6 +338,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_STAGGER: g_stagger = value; return NPM_OK;
         case NPM_TUNE_GEMM_GROUP_M: g_group_m = value > 0 ? value : 8; return NPM_OK;
         case 99: g_ablate = value; return NPM_OK;
+        case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }
 }
@@ -372,6 +376,12 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.e.ldr = g->ldr;
     a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) ? g->aux : nullptr;
     a.e.ldaux = g->ldaux;
+    {
+        const long lim = 1L << 31;
+        auto fits = [&](long ld) { return ((long)(g->m - 1) * ld + g->n) * 4 < lim; };
+        a.e.buf_ok = g_buf_epilogue && fits(g->ldc) && (!(epi & NPM_EPI_RESIDUAL) || fits(g->ldr)) &&
+                     (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) || fits(g->ldaux)) && fits(g->n);
+    }
     a.group_m = g_group_m;
     a.stagger = g_stagger;
     a.ablate = g_ablate;

@@ -28,6 +28,7 @@ struct Epilogue {
     float *aux;              // pre-activation out (RELU_SAVE) / mask in (RELU_MASK)
     long ldaux;
     float *ws;               // split-K slabs (raw accumulators), pitch N
+    int buf_ok;              // every extent (C, residual, aux, slab) < 2^31 bytes: buffer-instruction epilogue
 };
 
 // Bijective XCD-contiguous remap: blocks b and b+8 share an XCD (and its L2), so give each
@@ -157,6 +158,62 @@ __device__ __forceinline__ void write_tile(const f32x16 (&acc)[2][2], const Epil
                     if (relu) v = fmaxf(v, 0.f);
                     e.C[(long)row * e.ldc + col] = v;
                 }
+            }
+        }
+}
+
+// Branch-free epilogue through buffer instructions.  Each store is ONE instruction:
+// the per-lane column offset sits in the VGPR offset (computed once), the row offset is a
+// scalar (soffset) and rows >= M / columns >= N are dropped by the descriptor's range check
+// (out-of-range lanes carry an offset beyond num_records) -- no per-element address VALU,
+// no exec-mask juggling.  Requires every extent below 2^31 bytes (the host checks).
+__device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const Epilogue &e, bool raw,
+                                               int m0, int n0, int M, int N, int wm, int wn, int l32, int half) {
+    constexpr int OOB = 0x7FFFFFFF;
+    float *cptr = raw ? e.ws : e.C;
+    const int ldc = raw ? N : (int)e.ldc;
+    const int flags = raw ? 0 : e.flags;
+    const float alpha = raw ? 1.f : e.alpha;
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void *)cptr, 0, (int)(((long)(M - 1) * ldc + N) * 4), 0x00020000);
+    const bool has_bias = (flags & NPM_EPI_BIAS) != 0;
+    const bool has_res = (flags & NPM_EPI_RESIDUAL) != 0;
+    const bool relu_save = (flags & NPM_EPI_RELU_SAVE) != 0;
+    const bool relu_mask = (flags & NPM_EPI_RELU_MASK) != 0;
+    const bool relu = (flags & NPM_EPI_RELU) != 0;
+    const int ldr = has_res ? (int)e.ldr : 0;
+    const int ldx = (relu_save || relu_mask) ? (int)e.ldaux : 0;
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R : cptr), 0,
+                                                      has_res ? (int)(((long)(M - 1) * ldr + N) * 4) : 0, 0x00020000);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)((relu_save || relu_mask) ? e.aux : cptr), 0,
+                                                      (relu_save || relu_mask) ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
+    int vc[2], vr[2], vx[2];
+    float bias[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l32;
+        const bool ok = col < N;
+        vc[j] = ok ? (4 * half * ldc + col) * 4 : OOB;
+        vr[j] = ok ? (4 * half * ldr + col) * 4 : OOB;
+        vx[j] = ok ? (4 * half * ldx + col) * 4 : OOB;
+        bias[j] = (has_bias && ok) ? e.bias[col] : 0.f;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);       // wave-uniform
+            const int sc = row * ldc * 4, sr = row * ldr * 4, sx = row * ldx * 4;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float v = alpha * acc[i][j][r] + bias[j];
+                if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vr[j], sr, 0));
+                if (relu_save) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rx, vx[j], sx, 0);
+                    v = fmaxf(v, 0.f);
+                }
+                if (relu_mask) v = (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[j], sx, 0)) >= 0.f) ? v : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
             }
         }
 }

@@ -157,3 +157,25 @@ def test_bad_arguments_fail_loudly(D):
     from np_modeling_amd import _C
     with pytest.raises(_C.NpmError):
         D.gemm(8, 8, 8, D.Mat(0, 8), D.Mat(0, 8), D.Mat(0, 8))
+
+
+@pytest.mark.parametrize('ta,tb', [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize('m,n,k', [(64, 16, 32), (100, 200, 48), (129, 132, 16), (300, 4, 64)])
+def test_ragged_tiles_do_not_write_outside_c(D, ta, tb, m, n, k):
+    """The LDS-DMA kernel's epilogue relies on the buffer descriptor's range check to drop rows
+    >= M and columns >= N of edge tiles: C sits inside a guarded allocation whose sentinels must
+    survive, and C itself is pitched (ldc > n) with sentinels in the pitch gap."""
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((k, m) if ta else (m, k)).astype(np.float32)
+    b = rng.standard_normal((n, k) if tb else (k, n)).astype(np.float32)
+    ldc = n + 4
+    guard = 4096
+    whole = D.full([guard + m * ldc + guard], -777.0)
+    c = whole.flat_view(guard, [m, ldc])
+    D.gemm(m, n, k, D.Mat(D.from_host(a), a.shape[1]), D.Mat(D.from_host(b), b.shape[1]), D.Mat(c, ldc),
+           trans_a=ta, trans_b=tb)
+    host = whole.numpy()
+    assert np.all(host[:guard] == -777.0) and np.all(host[guard + m * ldc:] == -777.0)
+    body = host[guard:guard + m * ldc].reshape(m, ldc)
+    assert np.all(body[:, n:] == -777.0)
+    assert_close(body[:, :n], _ref(a, b, ta, tb), tol=2e-6)
