@@ -98,7 +98,7 @@ typedef struct npm_gemm {
 int npm_sgemm(const npm_gemm *g);
 
 /* Tuning knobs (A/B experiments in one process; defaults are the shipped configuration). */
-enum { NPM_TUNE_GEMM_PIPELINE = 0, NPM_TUNE_GEMM_STAGGER = 1, NPM_TUNE_GEMM_GROUP_M = 2, NPM_TUNE_GEMM_BUF_EPILOGUE = 3 };
+enum { NPM_TUNE_GEMM_PIPELINE = 0, NPM_TUNE_GEMM_STAGGER = 1, NPM_TUNE_GEMM_GROUP_M = 2, NPM_TUNE_GEMM_BUF_EPILOGUE = 3, NPM_TUNE_CONV_DMA = 4 };
 int npm_set_tuning(int knob, int value);
 
 /* ---- elementwise ---------------------------------------------------------- */

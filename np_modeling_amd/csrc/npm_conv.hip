@@ -205,6 +205,160 @@ conv_wgrad_kernel(const ConvArgs p) {
     }
 }
 
+// ---- LDS-DMA versions (same pipeline as sgemm_glds_kernel) ------------------------------------
+// The gather becomes a per-lane buffer offset: a lane whose tap falls outside the image gets an
+// offset beyond the descriptor's range and the hardware returns the zero of the padding.  The
+// descriptor is rebased per block to (first pixel - halo), so offsets stay small.
+constexpr int OOB_OFFSET = 0x7FFFFFFF;
+
+// forward / grad_x: requires C % 16 == 0 (a 16-deep K tile lies inside ONE tap), N % 4 == 0.
+__global__ void __launch_bounds__(NTHREADS, 4)
+conv_fwd_glds_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+
+    const int t = xcd_remap(blockIdx.x, gridDim.x);
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int halo = p.pad * p.W + p.pad;                   // pixels a tap can reach back / forward
+    const long first = (long)m0 - halo;                     // may be negative: never dereferenced
+    const long last = min((long)m0 + BM + halo, (long)p.M);
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.X + first * p.C), 0,
+                                                         (int)((last - first) * p.C * 4), 0x00020000);
+    const long b_left = ((long)(p.K - 1) * p.N + p.N - n0) * 4;
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.F + n0), 0, (int)min(b_left, 0x7FFFFFFEL), 0x00020000);
+
+    // this wave's two A pieces: rows 16 j + (lane >> 2), source chunk (lane & 3) ^ swizzle(row)
+    int rowv[2], ph[2], pw[2];
+    unsigned vbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = 16 * (2 * wave + i) + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        const int m = m0 + row;
+        rowv[i] = m;
+        pw[i] = m % p.W;
+        ph[i] = (m / p.W) % p.H;
+        vbase[i] = (unsigned)((row * p.C + c * 4) * 4);
+    }
+    const unsigned vb0 = glds_voffset<false>(lane, 2 * wave, p.N), vb1 = glds_voffset<false>(lane, 2 * wave + 1, p.N);
+    const int nkt = p.K / GK;
+
+    int c0 = 0, ti = 0, tj = 0;                             // tap / channel base of the NEXT tile to issue
+    auto issue = [&](int kt, int stage) {
+        float *sa = smem + stage * G_STAGE + (2 * wave) * 256;
+        float *sb = sa + G_TILE;
+        const int di = ti - p.pad, dj = tj - p.pad;
+        const unsigned soff = (unsigned)(((halo + di * p.W + dj) * p.C + c0) * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = rowv[i] < p.M && (unsigned)(ph[i] + di) < (unsigned)p.H && (unsigned)(pw[i] + dj) < (unsigned)p.W;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(sa + 256 * i), 16, ok ? vbase[i] : OOB_OFFSET, soff, 0, 0);
+        }
+        const unsigned kb = (unsigned)(kt * GK * p.N * 4);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)sb, 16, vb0, kb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(sb + 256), 16, vb1, kb, 0, 0);
+        c0 += GK;
+        if (c0 == p.C) { c0 = 0; if (++tj == p.ks) { tj = 0; ++ti; } }
+    };
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    if (nkt > 0) issue(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        const float *sA = smem + (kt & 1) * G_STAGE;
+        mma_tile16<true, false>(sA, sA + G_TILE, arow, brow, half, acc);
+    }
+    if (p.e.buf_ok) write_tile_buf(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+    else write_tile(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+}
+
+// grad_w: A(k = pixel, m' = (tap, c)) gathered M-major; requires C % 4 == 0, pixels % 16 == 0.
+__global__ void __launch_bounds__(NTHREADS, 4)
+conv_wgrad_glds_kernel(const ConvArgs p) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int t = logical % tiles, split = logical / tiles;
+    int tm, tn;
+    tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg) / GK;
+
+    const int halo = p.pad * p.W + p.pad;
+    const long first = (long)kbeg - halo;
+    const long last = min((long)kend + halo, (long)p.K);
+    const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.X + first * p.C), 0,
+                                                         (int)((last - first) * p.C * 4), 0x00020000);
+    const long b_left = ((long)(p.K - kbeg - 1) * p.N + p.N - n0) * 4;
+    const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.F + (long)kbeg * p.N + n0), 0,
+                                                         (int)min(b_left, 0x7FFFFFFEL), 0x00020000);
+    // this lane's 4 consecutive m' = (tap, c): fixed for the whole K loop
+    const int mq = m0 + (lane & 31) * 4;
+    const int tap = mq / p.C, c = mq - tap * p.C;
+    const int ti = tap / p.ks;
+    const int di = ti - p.pad, dj = tap - ti * p.ks - p.pad;
+    const bool m_ok = mq < p.M;
+    // its two pixel rows per tile: krow = 2 (2 wave + i) + (lane >> 5)
+    int ph[2], pw[2];
+    unsigned vbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int krow = 2 * (2 * wave + i) + (lane >> 5);
+        const int pix = kbeg + krow;
+        pw[i] = pix % p.W;
+        ph[i] = (pix / p.W) % p.H;
+        vbase[i] = (unsigned)(((krow + halo + di * p.W + dj) * p.C + c) * 4);
+    }
+    const int dw_ = GK % p.W, dh_ = GK / p.W;               // advance of (h, w) per 16 pixels
+    const unsigned vb0 = glds_voffset<false>(lane, 2 * wave, p.N), vb1 = glds_voffset<false>(lane, 2 * wave + 1, p.N);
+
+    auto issue = [&](int kt, int stage) {
+        float *sa = smem + stage * G_STAGE + (2 * wave) * 256;
+        float *sb = sa + G_TILE;
+        const unsigned ka = (unsigned)(kt * GK * p.C * 4), kb = (unsigned)(kt * GK * p.N * 4);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const bool ok = m_ok && (unsigned)(ph[i] + di) < (unsigned)p.H && (unsigned)(pw[i] + dj) < (unsigned)p.W;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(sa + 256 * i), 16, ok ? vbase[i] : OOB_OFFSET, ka, 0, 0);
+            pw[i] += dw_;
+            ph[i] += dh_;
+            if (pw[i] >= p.W) { pw[i] -= p.W; ++ph[i]; }
+            while (ph[i] >= p.H) ph[i] -= p.H;
+        }
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)sb, 16, vb0, kb, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(sb + 256), 16, vb1, kb, 0, 0);
+    };
+
+    f32x16 acc[2][2];
+    zero_acc(acc);
+    const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    if (nkt > 0) issue(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        const float *sA = smem + (kt & 1) * G_STAGE;
+        mma_tile16<false, false>(sA, sA + G_TILE, arow, brow, half, acc);
+    }
+    Epilogue e = p.e;
+    const bool raw = p.splits > 1;
+    if (raw) e.ws += (long)split * p.slab;
+    if (e.buf_ok) write_tile_buf(acc, e, raw, m0, n0, p.M, p.N, wm, wn, l32, half);
+    else write_tile(acc, e, raw, m0, n0, p.M, p.N, wm, wn, l32, half);
+}
+
 // out[(ti, tj, c1), c0] = filt[ks-1-ti, ks-1-tj, c0, c1]      (conv.py:130)
 __global__ void flip_transpose_filter_kernel(const float *__restrict__ filt, float *__restrict__ out,
                                              int ks, int c0, int c1) {
@@ -219,6 +373,8 @@ __global__ void flip_transpose_filter_kernel(const float *__restrict__ filt, flo
 }
 
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
+
+int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
 
 int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
                   const Epilogue &e) {
@@ -236,13 +392,20 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     NPM_ARG(grid < (1L << 31));
     const bool vec = c % 4 == 0 && n_out % 4 == 0 && aligned16(x) && aligned16(filt_kn);
     hipStream_t s = npm::ctx().stream;
-    if (vec) hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    const long halo = (long)a.pad * w + a.pad;
+    a.e.buf_ok = g_conv_dma && ((m - 1) * n_out + n_out) * 4 < (1L << 31);
+    const bool dma = g_conv_dma && vec && c % GK == 0 && (BM + 2 * halo) * c * 4 < (1L << 30) &&
+                     (long)a.K * n_out * 4 < (1L << 31);
+    if (dma) hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (vec) hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }
 
 }  // namespace
+
+extern "C" int npm_conv_set_dma(int on) { g_conv_dma = on; return NPM_OK; }
 
 extern "C" {
 
@@ -318,7 +481,13 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     const bool vec = c_in % 4 == 0 && c_out % 4 == 0 && aligned16(x) && aligned16(dy);
     hipStream_t s = npm::ctx().stream;
     const int grid = (int)(tiles * splits);
-    if (vec) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(NTHREADS), 0, s, a);
+    const long halo = (long)a.pad * w + a.pad;
+    a.e.buf_ok = g_conv_dma && (long)a.M * a.N * 4 < (1L << 31);
+    const bool dma = g_conv_dma && vec && pixels % GK == 0 && a.k_per_split % GK == 0 &&
+                     ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) &&
+                     (long)a.k_per_split * c_out * 4 < (1L << 30);
+    if (dma) hipLaunchKernelGGL(conv_wgrad_glds_kernel, dim3(grid), dim3(NTHREADS), 0, s, a);
+    else if (vec) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(NTHREADS), 0, s, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(NTHREADS), 0, s, a);
     NPM_CHECK_LAUNCH();
     if (splits > 1) {

@@ -153,37 +153,6 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // c' ^ ((r >> 2) & 3); reads apply the same XOR (conflict-free ds_read_b128).
 // Needs 16-byte aligned operands and K (and every split) a multiple of 16.
 // ------------------------------------------------------------------------------------------
-constexpr int GK = 16;                         // K step of the DMA pipeline
-constexpr int G_TILE = BM * GK;                // floats per operand tile (8 KB)
-constexpr int G_STAGE = 2 * G_TILE;            // A + B
-
-typedef __attribute__((address_space(3))) void lds_void;
-
-template <bool KMAJ>
-__device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
-    // byte offset of this lane's 16-byte chunk for wave-instruction j (0..7) of a tile, relative
-    // to the tile's first row (K-major) / first k row (MN-major), K offset excluded
-    if (KMAJ) {
-        const int row = 16 * j + (lane >> 2);
-        const int c = (lane & 3) ^ ((row >> 2) & 3);
-        return (unsigned)(row * ld * 4 + c * 16);
-    } else {
-        const int krow = 2 * j + (lane >> 5);
-        return (unsigned)(krow * ld * 4 + (lane & 31) * 16);
-    }
-}
-
-template <bool KMAJ>
-__device__ __forceinline__ float4 read_frag16(const float *__restrict__ s, int row, int g, int half) {
-    if (KMAJ) {
-        const int c = (2 * g + half) ^ ((row >> 2) & 3);
-        return *reinterpret_cast<const float4 *>(s + row * GK + c * 4);
-    } else {
-        const float *p = s + (8 * g + 4 * half) * BM + row;
-        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
-    }
-}
-
 template <bool A_KMAJ, bool B_KMAJ>
 __global__ void __launch_bounds__(NTHREADS, 4)
 sgemm_glds_kernel(const GemmArgs p) {
@@ -250,22 +219,7 @@ sgemm_glds_kernel(const GemmArgs p) {
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
         const float *sB = sA + G_TILE;
-#pragma unroll
-        for (int g = 0; g < GK / 8; ++g) {
-            const float4 a0 = read_frag16<A_KMAJ>(sA, arow, g, half);
-            const float4 a1 = read_frag16<A_KMAJ>(sA, arow + 32, g, half);
-            const float4 b0 = read_frag16<B_KMAJ>(sB, brow, g, half);
-            const float4 b1 = read_frag16<B_KMAJ>(sB, brow + 32, g, half);
-            const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
-            const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
-#pragma unroll
-            for (int s = 0; s < 4; ++s)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int j = 0; j < 2; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
-        }
+        mma_tile16<A_KMAJ, B_KMAJ>(sA, sB, arow, brow, half, acc);
     }
 
     Epilogue e = p.e;
@@ -332,6 +286,8 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 
 }  // namespace npm_tile
 
+extern "C" int npm_conv_set_dma(int on);
+
 extern "C" int npm_set_tuning(int knob, int value) {
     switch (knob) {
         case NPM_TUNE_GEMM_PIPELINE: g_pipe = value; return NPM_OK;
@@ -339,6 +295,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_GROUP_M: g_group_m = value > 0 ? value : 8; return NPM_OK;
         case 99: g_ablate = value; return NPM_OK;
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
+        case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }
 }

@@ -258,6 +258,60 @@ __device__ __forceinline__ void load_tile(const float *__restrict__ base, long l
     }
 }
 
+// ---- LDS-DMA pipeline pieces (K step 16, lane-linear LDS images) ------------------------------
+constexpr int GK = 16;                         // K step of the DMA pipeline
+constexpr int G_TILE = BM * GK;                // floats per operand tile (8 KB)
+constexpr int G_STAGE = 2 * G_TILE;            // A + B
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+template <bool KMAJ>
+__device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
+    // byte offset of this lane's 16-byte chunk for wave-instruction j (0..7) of a tile, relative
+    // to the tile's first row (K-major) / first k row (MN-major), K offset excluded
+    if (KMAJ) {
+        const int row = 16 * j + (lane >> 2);
+        const int c = (lane & 3) ^ ((row >> 2) & 3);
+        return (unsigned)(row * ld * 4 + c * 16);
+    } else {
+        const int krow = 2 * j + (lane >> 5);
+        return (unsigned)(krow * ld * 4 + (lane & 31) * 16);
+    }
+}
+
+template <bool KMAJ>
+__device__ __forceinline__ float4 read_frag16(const float *__restrict__ s, int row, int g, int half) {
+    if (KMAJ) {
+        const int c = (2 * g + half) ^ ((row >> 2) & 3);
+        return *reinterpret_cast<const float4 *>(s + row * GK + c * 4);
+    } else {
+        const float *p = s + (8 * g + 4 * half) * BM + row;
+        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+    }
+}
+
+// The 32 MFMAs of one 16-deep K tile for one wave.
+template <bool A_KMAJ, bool B_KMAJ>
+__device__ __forceinline__ void mma_tile16(const float *__restrict__ sA, const float *__restrict__ sB,
+                                           int arow, int brow, int half, f32x16 (&acc)[2][2]) {
+#pragma unroll
+    for (int g = 0; g < GK / 8; ++g) {
+        const float4 a0 = read_frag16<A_KMAJ>(sA, arow, g, half);
+        const float4 a1 = read_frag16<A_KMAJ>(sA, arow + 32, g, half);
+        const float4 b0 = read_frag16<B_KMAJ>(sB, brow, g, half);
+        const float4 b1 = read_frag16<B_KMAJ>(sB, brow + 32, g, half);
+        const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
+        const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][s], bv[j][s], acc[i][j], 0, 0, 0);
+    }
+}
+
 // Sum split-K slabs in split order and apply the linear part of the epilogue.
 struct ReduceArgs {
     const float *ws;
