@@ -90,6 +90,19 @@ def cpu_baseline(args, params):
                        'the reference-verbatim Jacobian form needs TBs at this width (BASELINE.md)')
 
 
+def load_pmc_traffic(args):
+    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/summarize_pmc.py); PMC
+    counters cannot be read from inside the process, so this is the value of the last profiled run of this same
+    default workload, or null for any other shape."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    default = (args.batch, args.seq, args.features, args.heads, args.hidden) == (256, 512, 1024, 8, 4096)
+    if not (default and os.path.exists(path)):
+        return None, None
+    with open(path) as f:
+        data = json.load(f)
+    return data['gemm_family_bytes_per_launch'], 'profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes; includes Infinity-Cache hits'
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -188,10 +201,13 @@ def main():
         g_flops = sum(v['flops'] for v in gemm.values())
         g_launches = sum(v['launches'] for v in gemm.values())
         achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
+        traffic, traffic_src = load_pmc_traffic(args)
         result['roofline'] = {
-            'kernel': 'sgemm_mfma_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family: NN/NT/TN)',
+            'kernel': 'sgemm_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family, LDS-DMA pipeline: NN/NT/TN)',
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
-            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': None,
+            'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
+            'traffic_source': traffic_src,
+            'algorithmic_bytes_per_launch': sum(v['bytes'] for v in gemm.values()) / max(g_launches, 1),
             'launches': g_launches, 'avg_launch_ms': g_ms / max(g_launches, 1),
             'share_of_step_time': g_ms / (1e3 * elapsed) if elapsed > 0 else None,
             'by_layout': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],

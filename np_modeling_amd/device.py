@@ -449,7 +449,9 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
     g.epilogue = epi
     g.split_k = int(split_k)
     layout = 'TN' if trans_a else ('NT' if trans_b else 'NN')
-    with _timed('sgemm_' + layout, flops=2.0 * m * n * k * batch[0] * batch[1]):
+    nb = batch[0] * batch[1]
+    unique = 4.0 * nb * (m * k + k * n + m * n * (1 + (residual is not None) + (relu_save is not None) + (relu_mask is not None)))
+    with _timed('sgemm_' + layout, flops=2.0 * m * n * k * nb, nbytes=unique):
         _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
 
 

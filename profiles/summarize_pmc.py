@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""HBM-side traffic of the GEMM family from two rocprofv3 PMC passes of bench.py.
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d A -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d B -- python3 bench.py ... (same)
+    python profiles/summarize_pmc.py A/*/*_counter_collection.csv B/*/*_counter_collection.csv > profiles/pmc_traffic.json
+
+Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: both counters are in KiB; on gfx950
+FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced streaming reads, so it is doubled;
+WRITE_SIZE is exact.  FETCH_SIZE counts the L2's fabric-side requests: Infinity-Cache hits are included, so this is
+an upper bound of true HBM reads.  The K-major DMA loads of this kernel are 64-byte segments per row, for which the
+doubling may over-count (calibration: softmax/LayerNorm rows in the same run read exactly their algorithmic bytes
+after doubling)."""
+
+import collections
+import csv
+import json
+import sys
+
+
+def per_kernel(path):
+    out = collections.OrderedDict()
+    for r in csv.DictReader(open(path)):
+        out.setdefault(r['Kernel_Name'], []).append(float(r['Counter_Value']))
+    return out
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+    kernels = {}
+    for name in fetch:
+        short = name.replace('(anonymous namespace)::', '').replace('void ', '')
+        f, w = fetch[name], write.get(name, [0.0])
+        kernels[short] = dict(launches=len(f), fetch_kib_raw_per_launch=sum(f) / len(f), write_kib_per_launch=sum(w) / len(w),
+                              bytes_per_launch=(2 * sum(f) / len(f) + sum(w) / len(w)) * 1024)
+    gemm = {k: v for k, v in kernels.items() if k.startswith('sgemm_')}
+    n = sum(v['launches'] for v in gemm.values())
+    family = sum(v['bytes_per_launch'] * v['launches'] for v in gemm.values()) / max(n, 1)
+    print(json.dumps(dict(gemm_family_bytes_per_launch=family, gemm_family_launches=n, kernels=kernels,
+                          note='FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact, KiB units; includes Infinity-Cache hits'),
+                     indent=1))
+
+
+if __name__ == '__main__':
+    main()
