@@ -143,6 +143,21 @@ int npm_conv2d_bwd_x(const float *dy, const float *filt, float *dx,
 int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
                      int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
 
+/* ---- around the path ("next" rows of SURVEY.md section 8f): keeps a Trainer step on the device ---- */
+/* Adam with the reference's numerics (optimizer.py:53-67): fp64 moments m, v (device buffers of n doubles,
+ * zero-initialised with npm_fill_f64), bias correction with step >= 1, epsilon inside the sqrt */
+int npm_adam_step(float *var, const float *grad, double *m, double *v, size_t n, double lr, double beta1,
+                  double beta2, double eps, int step);
+int npm_fill_f64(double *dst, double value, size_t n);
+/* MSELoss (loss.py:21-29): loss = sum((y-t)^2)/n (fp64 accumulation, returned to the host); dy = 2 (y-t) / n */
+int npm_mse_fwd(const float *y, const float *targets, size_t n, double *loss);
+int npm_mse_bwd(const float *y, const float *targets, float *dy, size_t n);
+/* CrossEntropyLoss (loss.py:33-39): loss = -sum(t log y); dy = -t / y */
+int npm_xent_fwd(const float *y, const float *targets, size_t n, double *loss);
+int npm_xent_bwd(const float *y, const float *targets, float *dy, size_t n);
+/* DropOut (normalizations.py:14-30): y = mask ? x / keep_prob : 0 with a host-drawn byte mask */
+int npm_mask_scale(const float *x, const unsigned char *mask, float *y, size_t n, float keep_prob);
+
 #ifdef __cplusplus
 }
 #endif

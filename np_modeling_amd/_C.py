@@ -88,6 +88,13 @@ SIGNATURES = {
     'npm_conv2d_fwd': [C.POINTER(npm_conv2d)],
     'npm_conv2d_bwd_x': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
     'npm_conv2d_bwd_w': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
+    'npm_adam_step': [_P, _P, _P, _P, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int],
+    'npm_fill_f64': [_P, C.c_double, _SZ],
+    'npm_mse_fwd': [_P, _P, _SZ, C.POINTER(C.c_double)],
+    'npm_mse_bwd': [_P, _P, _P, _SZ],
+    'npm_xent_fwd': [_P, _P, _SZ, C.POINTER(C.c_double)],
+    'npm_xent_bwd': [_P, _P, _P, _SZ],
+    'npm_mask_scale': [_P, _P, _P, _SZ, _F],
 }
 _SPECIAL = {
     'npm_abi_version': (C.c_int, []),

@@ -212,6 +212,14 @@ sgemm_glds_kernel(const GemmArgs p) {
     const int arow = wm * 64 + l32;
     const int brow = wn * 64 + l32;
 
+    if (p.stagger && blockIdx.x < 1024) {
+        // The 4 blocks that share a CU start together, run equal work and would reach their epilogues
+        // (a store burst with the matrix pipe idle) together, generation after generation.  Delaying
+        // residency slot s of the FIRST generation by s * stagger de-phases the slots for the whole launch.
+        const int mode = p.stagger / 1000, units = p.stagger % 1000;
+        const int slot = mode == 0 ? (blockIdx.x >> 8) : mode == 1 ? ((blockIdx.x >> 3) & 3) : mode == 2 ? ((blockIdx.x >> 5) & 3) : ((blockIdx.x >> 6) & 3);
+        for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(16);     // 1024 cycles each
+    }
     if (nkt > 0) issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         // tile kt has landed (every wave's pieces) and everybody is done reading the other stage

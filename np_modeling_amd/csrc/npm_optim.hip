@@ -1,0 +1,168 @@
+// "Next" rows of the scope table: the pieces around the layer hot path
+// that keep a training step on the device -- Adam with the reference's numerics, the losses and
+// the dropout mask application.  All HBM-bound, float4 / grid-stride, one pass over the data.
+#include <algorithm>
+
+#include "npm_internal.h"
+
+namespace {
+
+inline int grid_for(size_t n, int cap = 4096) {
+    return (int)std::max<size_t>(1, std::min<size_t>((n + 255) / 256, (size_t)cap));
+}
+
+// reference optimizer.py:53-67 -- fp64 moments, bias correction, epsilon INSIDE the square root,
+// the fp64 update rounded to the parameter's fp32 when it is subtracted in place.
+__global__ void __launch_bounds__(256)
+adam_kernel(float *__restrict__ var, const float *__restrict__ grad, double *__restrict__ m, double *__restrict__ v,
+            size_t n, double lr, double beta1, double beta2, double eps, double corr1, double corr2) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const double g = (double)grad[i];
+        const double nm = beta1 * m[i] + (1.0 - beta1) * g;
+        const double nv = beta2 * v[i] + (1.0 - beta2) * g * g;
+        m[i] = nm;
+        v[i] = nv;
+        const double step = lr * ((nm / corr1) / sqrt(nv / corr2 + eps));
+        var[i] = var[i] - (float)step;           // numpy: float32 -= float64 array -> cast, then subtract
+    }
+}
+
+// per-block fp64 partial sums of f(a, b); a second launch of the same kernel reduces the partials
+template <int MODE>   // 0: (a-b)^2   1: -b*log(a)
+__global__ void __launch_bounds__(256)
+pair_sum_kernel(const float *__restrict__ a, const float *__restrict__ b, size_t n, double *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        if (MODE == 0) { const double d = (double)a[i] - (double)b[i]; s += d * d; }
+        else s -= (double)b[i] * log((double)a[i]);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+sum_f64_kernel(const double *__restrict__ in, int n, double *__restrict__ out) {
+    __shared__ double red[256];
+    double s = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) s += in[i];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[0] = red[0];
+}
+
+__global__ void __launch_bounds__(256)
+mse_bwd_kernel(const float *__restrict__ y, const float *__restrict__ t, float *__restrict__ dy, size_t n, float scale) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dy[i] = scale * (y[i] - t[i]);
+}
+
+__global__ void __launch_bounds__(256)
+xent_bwd_kernel(const float *__restrict__ y, const float *__restrict__ t, float *__restrict__ dy, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dy[i] = -t[i] / y[i];
+}
+
+__global__ void __launch_bounds__(256)
+mask_scale_kernel(const float *__restrict__ x, const unsigned char *__restrict__ mask, float *__restrict__ y,
+                  size_t n, float keep) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        y[i] = mask[i] ? x[i] / keep : 0.f;
+}
+
+template <int MODE>
+int pair_sum(const float *a, const float *b, size_t n, double *host_out) {
+    hipStream_t s = npm::ctx().stream;
+    const int blocks = grid_for(n, 1024);
+    npm::Scratch part;
+    int rc = part.alloc(sizeof(double) * (blocks + 1));
+    if (rc) return rc;
+    double *p = (double *)part.ptr;
+    hipLaunchKernelGGL(pair_sum_kernel<MODE>, dim3(blocks), dim3(256), 0, s, a, b, n, p + 1);
+    NPM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(sum_f64_kernel, dim3(1), dim3(256), 0, s, (const double *)(p + 1), blocks, p);
+    NPM_CHECK_LAUNCH();
+    return npm_d2h(host_out, p, sizeof(double));
+}
+
+}  // namespace
+
+extern "C" {
+
+int npm_adam_step(float *var, const float *grad, double *m, double *v, size_t n, double lr, double beta1,
+                  double beta2, double eps, int step) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(step >= 1);
+    if (n == 0) return NPM_OK;
+    NPM_ARG(var && grad && m && v);
+    const double corr1 = 1.0 - pow(beta1, (double)step), corr2 = 1.0 - pow(beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(256), 0, npm::ctx().stream, var, grad, m, v, n, lr, beta1,
+                       beta2, eps, corr1, corr2);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_fill_f64(double *dst, double value, size_t n) {
+    NPM_REQUIRE_INIT();
+    if (n == 0) return NPM_OK;
+    NPM_ARG(dst != nullptr);
+    if (value == 0.0) {
+        NPM_HIP(hipMemsetAsync(dst, 0, n * sizeof(double), npm::ctx().stream));
+        return NPM_OK;
+    }
+    return npm::fail(NPM_E_UNSUPPORTED, "npm_fill_f64: only 0.0 is supported");
+}
+
+int npm_mse_fwd(const float *y, const float *targets, size_t n, double *loss) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(loss != nullptr && n > 0 && y && targets);
+    int rc = pair_sum<0>(y, targets, n, loss);
+    if (rc) return rc;
+    *loss /= (double)n;
+    return NPM_OK;
+}
+
+int npm_mse_bwd(const float *y, const float *targets, float *dy, size_t n) {
+    NPM_REQUIRE_INIT();
+    if (n == 0) return NPM_OK;
+    NPM_ARG(y && targets && dy);
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, npm::ctx().stream, y, targets, dy, n,
+                       (float)(2.0 / (double)n));
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_xent_fwd(const float *y, const float *targets, size_t n, double *loss) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(loss != nullptr && n > 0 && y && targets);
+    return pair_sum<1>(y, targets, n, loss);
+}
+
+int npm_xent_bwd(const float *y, const float *targets, float *dy, size_t n) {
+    NPM_REQUIRE_INIT();
+    if (n == 0) return NPM_OK;
+    NPM_ARG(y && targets && dy);
+    hipLaunchKernelGGL(xent_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, npm::ctx().stream, y, targets, dy, n);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_mask_scale(const float *x, const unsigned char *mask, float *y, size_t n, float keep_prob) {
+    NPM_REQUIRE_INIT();
+    if (n == 0) return NPM_OK;
+    NPM_ARG(x && mask && y && keep_prob > 0.f);
+    hipLaunchKernelGGL(mask_scale_kernel, dim3(grid_for(n)), dim3(256), 0, npm::ctx().stream, x, mask, y, n, keep_prob);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+}  // extern "C"

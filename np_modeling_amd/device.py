@@ -312,6 +312,24 @@ def from_host(value) -> DeviceArray:
     return out
 
 
+class ByteBuffer:
+    """Raw device bytes (dropout masks)."""
+
+    __slots__ = ('_buf', 'ptr', 'nbytes')
+
+    def __init__(self, nbytes: int):
+        self._buf = _Buffer(nbytes)
+        self.ptr, self.nbytes = self._buf.ptr, int(nbytes)
+
+
+def bytes_from_host(value: np.ndarray) -> ByteBuffer:
+    host = np.ascontiguousarray(value).view(np.uint8)
+    out = ByteBuffer(host.nbytes)
+    if host.nbytes:
+        _C.check(_C.lib().npm_h2d(out.ptr, host.ctypes.data, host.nbytes), 'npm_h2d')
+    return out
+
+
 def as_device(value) -> DeviceArray:
     """DeviceArray as is; ``Scaled`` materialised; anything else (np.ndarray, jax Array,
     nested lists) copied to the device as contiguous fp32."""

@@ -6,6 +6,7 @@ from typing import Optional
 
 import numpy as np
 
+from np_modeling_amd import _C
 from np_modeling_amd import device as D
 from np_modeling_amd import parallel
 from np_modeling_amd.layers import layer
@@ -14,25 +15,32 @@ from np_modeling_amd.layers import layer
 class DropOut(layer.Layer):
     """``drop_prob == 0`` is the identity and returns its argument unchanged
     (normalizations.py:14-23) -- the only path the encoder exercises.  For p > 0 the mask is
-    drawn on the host with the reference's exact call (``np.random.binomial``), so a seeded
-    run drops the same elements; the masking itself is host arithmetic (outside the hot
-    path)."""
+    drawn on the HOST with the reference's exact call (``np.random.binomial``), so a seeded run
+    drops the same elements and ``_mask`` stays a readable NumPy array (reference
+    layers/normalizations_test.py:15-30 reads it); applying it is one device kernel."""
 
     def __init__(self, drop_prob: float, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._drop_prob = drop_prob
 
+    def _apply(self, x):
+        keep = 1 - self._drop_prob
+        x = D.as_device(x)
+        out = D.empty(x.shape)
+        _C.check(_C.lib().npm_mask_scale(x.ptr, self._mask_dev.ptr, out.ptr, x.size, float(keep)), 'npm_mask_scale')
+        return out
+
     def forward(self, x, training: bool = True):
         if training and self._drop_prob != 0.0:
             keep = 1 - self._drop_prob
             self._mask = np.random.binomial(n=1, p=keep, size=x.size).reshape(x.shape)
-            return D.as_device(np.where(self._mask, np.asarray(x) / keep, 0.0))
+            self._mask_dev = D.bytes_from_host(self._mask.astype(np.uint8))
+            return self._apply(x)
         return x
 
     def backward(self, dl_dy, *args, **kwargs):
         if self._drop_prob != 0.0:
-            keep = 1 - self._drop_prob
-            return D.as_device(np.where(self._mask, np.asarray(dl_dy) / keep, 0.0))
+            return self._apply(dl_dy)
         return dl_dy
 
 

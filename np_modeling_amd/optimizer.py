@@ -6,8 +6,9 @@ reference's own unchanged ``optimizer.py`` also drives the device layers (``Devi
 implements ``lr * grad`` and ``-=``); these classes are the same contract for machines
 where the reference is not on the path, with the SGD step as a single device axpy.
 Adam keeps the reference's numerics -- epsilon INSIDE the square root, bias correction,
-fp64 moments keyed by ``f'{id(obj)}.{attribute}'`` -- and computes them on the host
-(a device Adam is "next").
+fp64 moments keyed by ``f'{id(obj)}.{attribute}'``.  When parameter and gradient live on the
+device the whole update is one kernel (``npm_adam_step``) on device-resident fp64 moments;
+host arrays take the NumPy path.
 """
 
 from __future__ import annotations
@@ -52,8 +53,40 @@ class AdamOptimizerConfig:
         self._velocities = {}
 
 
+class _DeviceMoments:
+    """fp64 first/second moments of one parameter, resident in HBM."""
+
+    def __init__(self, n: int):
+        from np_modeling_amd import _C, device as D
+        self.n = n
+        self.m = D._Buffer(8 * n)
+        self.v = D._Buffer(8 * n)
+        _C.check(_C.lib().npm_fill_f64(self.m.ptr, 0.0, n), 'npm_fill_f64')
+        _C.check(_C.lib().npm_fill_f64(self.v.ptr, 0.0, n), 'npm_fill_f64')
+
+
 class AdamOptimizer(AdamOptimizerConfig, Optimizer):
+    def _device_step(self, identifier, variable, gradient):
+        from np_modeling_amd import _C, device as D
+        if isinstance(gradient, D.Scaled):
+            gradient = gradient.materialize()
+        step = self._steps.get(identifier, 1)
+        state = self._momentums.get(identifier)
+        if not isinstance(state, _DeviceMoments) or state.n != variable.size:
+            state = _DeviceMoments(variable.size)
+        _C.check(_C.lib().npm_adam_step(variable.ptr, gradient.ptr, state.m.ptr, state.v.ptr, variable.size,
+                                        float(self.learning_rate), float(self.beta1), float(self.beta2),
+                                        float(self.epsilon), int(step)), 'npm_adam_step')
+        self._steps[identifier] = step + 1
+        self._momentums[identifier] = state
+        self._velocities[identifier] = state
+        return variable
+
     def update_variable(self, identifier, variable, gradient):
+        from np_modeling_amd import device as D
+        if isinstance(variable, D.DeviceArray) and isinstance(gradient, (D.DeviceArray, D.Scaled)) \
+                and gradient.size == variable.size:
+            return self._device_step(identifier, variable, gradient)
         grad = np.asarray(gradient, dtype=np.float64)
         step = self._steps.get(identifier, 1)
         first = self._momentums.get(identifier)

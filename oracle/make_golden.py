@@ -129,6 +129,45 @@ def gen_encoder(layers, norm_first, name):
          heads=np.int64(4), hidden=np.int64(96), lr=np.float64(1e-3), **p0, **p1)
 
 
+def gen_decoder(layers, norm_first, name):
+    np.random.seed(0)
+    dec = layers.TransformerDecoder(num_heads=4, hidden_units=80, norm_first=norm_first)
+    q = rand([3, 12, 48])
+    kv = rand([3, 20, 48])
+    out = dec(q, kv)
+    names = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+    subs = {'sa_' + n: (dec._self_attention, '_' + n) for n in names}
+    subs.update({'ca_' + n: (dec._cross_attention, '_' + n) for n in names})
+    for i, norm in enumerate([dec._norm1, dec._norm2, dec._norm3], start=1):
+        subs[f'n{i}_gamma'] = (norm, '_gamma')
+        subs[f'n{i}_beta'] = (norm, '_beta')
+    subs.update(d1_w=(dec._dense1._linear, '_w'), d1_b=(dec._dense1._linear, '_b'),
+                d2_w=(dec._dense2, '_w'), d2_b=(dec._dense2, '_b'))
+    p0 = {k + '__0': getattr(o, a).copy() for k, (o, a) in subs.items()}
+    dy = rand(out.shape) * 0.05
+    dq, dkv = dec(dy, backprop=True, learning_rate=1e-3)
+    p1 = {k + '__1': getattr(o, a) for k, (o, a) in subs.items()}
+    save(name, q=q, kv=kv, out=out, dy=dy, dq=dq, dkv=dkv, norm_first=np.bool_(norm_first), heads=np.int64(4),
+         hidden=np.int64(80), lr=np.float64(1e-3), **p0, **p1)
+
+
+def gen_losses(loss):
+    """loss_test.py:15-66 shapes: [128, 32]."""
+    np.random.seed(0)
+    y = rand([128, 32])
+    t = rand([128, 32])
+    mse = loss.MSELoss()
+    value = mse(y, t)
+    grad = mse(backprop=True)
+    prob = np.exp(y) / np.exp(y).sum(axis=-1, keepdims=True)
+    onehot = np.eye(32, dtype=np.float32)[np.random.randint(0, 32, size=128)]
+    ce = loss.CrossEntropyLoss()
+    ce_value = ce(prob, onehot)
+    ce_grad = ce(backprop=True)
+    save('losses', y=y, t=t, mse=np.float64(value), mse_grad=grad, prob=prob, onehot=onehot,
+         ce=np.float64(ce_value), ce_grad=ce_grad)
+
+
 def gen_train(layers, optimizer, train):
     """train_test.py:14-49 flow; the printed losses are the known answers."""
     import re
@@ -165,6 +204,9 @@ def main():
     gen_mha(layers, 3, 10, 28, 48, 4, 'mha_cross')
     gen_encoder(layers, True, 'encoder_prenorm')
     gen_encoder(layers, False, 'encoder_postnorm')
+    gen_decoder(layers, True, 'decoder_prenorm')
+    gen_decoder(layers, False, 'decoder_postnorm')
+    gen_losses(loss)
     gen_train(layers, optimizer, train)
 
 

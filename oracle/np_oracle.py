@@ -429,6 +429,89 @@ def encoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3,
 
 
 # --------------------------------------------------------------------------- #
+# TransformerDecoder (reference layers/transformer.py:117-203), drop_rate == 0
+# --------------------------------------------------------------------------- #
+def _att(p, tag):
+    return {name: p[f'{tag}_{name}'] for name in MHA_PARAM_NAMES}
+
+
+def decoder_fwd(p: Dict[str, Array], q: Array, kv: Array, norm_first: bool, eps: float = 1e-3,
+                verbatim: bool = False):
+    """Self-attention, cross-attention over kv, feed-forward (transformer.py:117-158).
+    Params: sa_*, ca_* (attention), n1/n2/n3_{gamma,beta}, d1_w/b, d2_w/b."""
+    b, s, f = q.shape
+    c: Dict[str, object] = {}
+    skip = q
+    h = q
+    if norm_first:
+        c['n1_x'] = h
+        h, c['n1'] = layernorm_fwd(h, p['n1_gamma'], p['n1_beta'], eps)
+    out, c['sa'] = mha_fwd(_att(p, 'sa'), h, verbatim=verbatim)
+    out = out + skip
+    if not norm_first:
+        c['n1_x'] = out
+        out, c['n1'] = layernorm_fwd(out, p['n1_gamma'], p['n1_beta'], eps)
+    skip = out
+    if norm_first:
+        c['n2_x'] = out
+        out, c['n2'] = layernorm_fwd(out, p['n2_gamma'], p['n2_beta'], eps)
+    out, c['ca'] = mha_fwd(_att(p, 'ca'), out, kv, verbatim=verbatim)
+    out = out + skip
+    if not norm_first:
+        c['n2_x'] = out
+        out, c['n2'] = layernorm_fwd(out, p['n2_gamma'], p['n2_beta'], eps)
+    out = out.reshape(-1, f)
+    skip = out
+    if norm_first:
+        c['n3_x'] = out
+        out, c['n3'] = layernorm_fwd(out, p['n3_gamma'], p['n3_beta'], eps)
+    c['d1_x'] = out
+    out, c['d1_pre'] = dense_fwd(out, p['d1_w'], p['d1_b'])
+    c['d2_x'] = out
+    out = linear_fwd(out, p['d2_w'], p['d2_b']) + skip
+    if not norm_first:
+        c['n3_x'] = out
+        out, c['n3'] = layernorm_fwd(out, p['n3_gamma'], p['n3_beta'], eps)
+    return out.reshape(b, s, f), c
+
+
+def decoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3, verbatim: bool = False):
+    """Returns ((dq, dkv), grads); dkv = dkey + dvalue of the cross-attention (transformer.py:160-203)."""
+    b, s, f = dy.shape
+    g: Dict[str, Array] = {}
+    dy = dy.reshape(-1, f)
+    if not norm_first:
+        dy, g['n3_gamma'], g['n3_beta'] = layernorm_bwd(c['n3_x'], p['n3_gamma'], eps, c['n3'], dy, verbatim)
+    dskip = dy
+    dy, g['d2_w'], g['d2_b'] = linear_bwd(c['d2_x'], p['d2_w'], dy)
+    dy, g['d1_w'], g['d1_b'] = dense_bwd(c['d1_x'], p['d1_w'], c['d1_pre'], dy)
+    if norm_first:
+        dy, g['n3_gamma'], g['n3_beta'] = layernorm_bwd(c['n3_x'], p['n3_gamma'], eps, c['n3'], dy, verbatim)
+    dy = (dy + dskip).reshape(b, s, f)
+    if not norm_first:
+        dy, g['n2_gamma'], g['n2_beta'] = layernorm_bwd(c['n2_x'], p['n2_gamma'], eps, c['n2'], dy, verbatim)
+    dskip = dy
+    (dq, dk, dv), ga = mha_bwd(_att(p, 'ca'), c['ca'], dy, verbatim=verbatim)
+    for name, arr in ga.items():
+        g[f'ca_{name}'] = arr
+    dkv = dk + dv
+    dy = dq
+    if norm_first:
+        dy, g['n2_gamma'], g['n2_beta'] = layernorm_bwd(c['n2_x'], p['n2_gamma'], eps, c['n2'], dy, verbatim)
+    dy = dy + dskip
+    if not norm_first:
+        dy, g['n1_gamma'], g['n1_beta'] = layernorm_bwd(c['n1_x'], p['n1_gamma'], eps, c['n1'], dy, verbatim)
+    dskip = dy
+    (dq, dk, dv), ga = mha_bwd(_att(p, 'sa'), c['sa'], dy, verbatim=verbatim)
+    for name, arr in ga.items():
+        g[f'sa_{name}'] = arr
+    dy = dq + dk + dv
+    if norm_first:
+        dy, g['n1_gamma'], g['n1_beta'] = layernorm_bwd(c['n1_x'], p['n1_gamma'], eps, c['n1'], dy, verbatim)
+    return (dy + dskip, dkv), g
+
+
+# --------------------------------------------------------------------------- #
 # optimizers and losses (reference optimizer.py:26-69, loss.py:20-39)
 # --------------------------------------------------------------------------- #
 def sgd_step(param: Array, grad: Array, lr: float) -> Array:
@@ -451,6 +534,16 @@ def adam_step(param, grad, state: dict, lr, beta1=0.9, beta2=0.999, eps=1e-7):
     out -= (lr * (m_hat / np.sqrt(v_hat + eps))).astype(param.dtype)
     state.update(t=t + 1, m=m, v=v)
     return out
+
+
+def xent_fwd(y, targets):
+    """-sum(t log y) (loss.py:33-36)."""
+    return -np.sum(targets * np.log(y))
+
+
+def xent_bwd(y, targets):
+    """-t / y (loss.py:38-39)."""
+    return -targets / y
 
 
 def mse_fwd(y, targets):

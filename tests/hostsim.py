@@ -231,6 +231,49 @@ class HostSim:
         return 0
 
 
+    # ---- around the path -------------------------------------------------------------------------
+    def npm_fill_f64(self, dst, value, n):
+        np.ctypeslib.as_array((C.c_double * int(n)).from_address(_addr(dst)))[:] = value
+        return 0
+
+    def npm_adam_step(self, var, grad, m, v, n, lr, beta1, beta2, eps, step):
+        n = int(n)
+        mm = np.ctypeslib.as_array((C.c_double * n).from_address(_addr(m)))
+        vv = np.ctypeslib.as_array((C.c_double * n).from_address(_addr(v)))
+        g = _vec(grad, n).astype(np.float64)
+        mm[:] = beta1 * mm + (1 - beta1) * g
+        vv[:] = beta2 * vv + (1 - beta2) * g ** 2
+        upd = lr * ((mm / (1 - beta1 ** step)) / np.sqrt(vv / (1 - beta2 ** step) + eps))
+        w = _vec(var, n)
+        w -= upd.astype(np.float32)
+        return 0
+
+    def npm_mse_fwd(self, y, t, n, out):
+        d = _vec(y, n).astype(np.float64) - _vec(t, n)
+        _deref(out).value = float((d * d).sum() / int(n))
+        return 0
+
+    def npm_mse_bwd(self, y, t, dy, n):
+        _vec(dy, n)[:] = np.float32(2.0 / int(n)) * (_vec(y, n) - _vec(t, n))
+        return 0
+
+    def npm_xent_fwd(self, y, t, n, out):
+        _deref(out).value = float(-(_vec(t, n).astype(np.float64) * np.log(_vec(y, n).astype(np.float64))).sum())
+        return 0
+
+    def npm_xent_bwd(self, y, t, dy, n):
+        _vec(dy, n)[:] = -_vec(t, n) / _vec(y, n)
+        return 0
+
+    def npm_mask_scale(self, x, mask, y, n, keep):
+        mk = np.ctypeslib.as_array((C.c_ubyte * int(n)).from_address(_addr(mask)))
+        _vec(y, n)[:] = np.where(mk != 0, _vec(x, n) / np.float32(keep), 0)
+        return 0
+
+    def npm_set_tuning(self, knob, value):
+        return 0
+
+
 def install():
     """Install a fresh simulator as the product's library handle; returns it."""
     from np_modeling_amd import _C
