@@ -93,12 +93,23 @@ typedef struct npm_gemm {
     const float *residual; int64_t ldr;  /* same batch strides as C */
     float *aux; int64_t ldaux;           /* same batch strides as C */
     int32_t split_k;                     /* 0 = choose automatically, 1 = never split */
+    float *colsum;                       /* optional [batch1, n]: colsum[z1, j] = sum over z0 and rows of the stored C
+                                            (the bias gradient np.sum(dy, axis=0), mlp.py:34 / attentions.py:190-197,
+                                            taken in the producing GEMM's epilogue; fixed summation order) */
 } npm_gemm;
 
 int npm_sgemm(const npm_gemm *g);
 
-/* Tuning knobs (A/B experiments in one process; defaults are the shipped configuration). */
-enum { NPM_TUNE_GEMM_PIPELINE = 0, NPM_TUNE_GEMM_STAGGER = 1, NPM_TUNE_GEMM_GROUP_M = 2, NPM_TUNE_GEMM_BUF_EPILOGUE = 3, NPM_TUNE_CONV_DMA = 4 };
+/* Tuning knobs for A/B experiments in one process (tools/gemm_bench.py --tune, NPM_TUNE=knob=value,...).
+ * Defaults are the shipped configuration: LDS-DMA pipeline (2), tile-row groups of 8, buffer epilogue on,
+ * convolution DMA on.  NPM_TUNE_GEMM_ABLATE is a timing-only diagnostic: it skips work and breaks results. */
+enum {
+    NPM_TUNE_GEMM_PIPELINE = 0,      /* 0 register-staged 2 barriers, 1 register-staged double buffer, 2 LDS-DMA */
+    NPM_TUNE_GEMM_GROUP_M = 2,
+    NPM_TUNE_GEMM_BUF_EPILOGUE = 3,
+    NPM_TUNE_CONV_DMA = 4,
+    NPM_TUNE_GEMM_ABLATE = 99
+};
 int npm_set_tuning(int knob, int value);
 
 /* ---- elementwise ---------------------------------------------------------- */

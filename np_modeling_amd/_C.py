@@ -35,6 +35,7 @@ class npm_gemm(C.Structure):
         ('residual', C.c_void_p), ('ldr', C.c_int64),
         ('aux', C.c_void_p), ('ldaux', C.c_int64),
         ('split_k', C.c_int32),
+        ('colsum', C.c_void_p),
     ]
 
 

@@ -38,14 +38,12 @@ struct GemmArgs {
     int batch1;
     int tiles_m, tiles_n, splits, k_per_split;
     int group_m;
-    int stagger;     // 0 = off, else blocks per residency generation (tuning knob)
-    int ablate;      // timing-only experiments: 1 skip global loads, 2 skip LDS stores, 4 skip barriers
+    int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers
     long slab;       // split-K: batch * M * N
     Epilogue e;
 };
 
 int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline where eligible
-int g_stagger = 0;
 int g_group_m = 8;
 int g_ablate = 0;
 int g_buf_epilogue = 1;
@@ -81,13 +79,6 @@ sgemm_mfma_kernel(const GemmArgs p) {
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nkt = (kend - kbeg + BK - 1) / BK;
-
-    if (p.stagger && blockIdx.x < 3 * 256) {
-        // de-phase the first generation of blocks that share a CU: identical blocks started together
-        // reach their barriers and LDS refills together and leave the matrix pipe idle meanwhile
-        const int slot = blockIdx.x / 256;
-        for (int i = 0; i < slot * p.stagger; ++i) __builtin_amdgcn_s_sleep(16);     // 1024 cycles each
-    }
 
     f32x16 acc[2][2];
     zero_acc(acc);
@@ -153,7 +144,7 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // c' ^ ((r >> 2) & 3); reads apply the same XOR (conflict-free ds_read_b128).
 // Needs 16-byte aligned operands and K (and every split) a multiple of 16.
 // ------------------------------------------------------------------------------------------
-template <bool A_KMAJ, bool B_KMAJ>
+template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM>
 __global__ void __launch_bounds__(NTHREADS, 4)
 sgemm_glds_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
@@ -212,19 +203,11 @@ sgemm_glds_kernel(const GemmArgs p) {
     const int arow = wm * 64 + l32;
     const int brow = wn * 64 + l32;
 
-    if (p.stagger && blockIdx.x < 1024) {
-        // The 4 blocks that share a CU start together, run equal work and would reach their epilogues
-        // (a store burst with the matrix pipe idle) together, generation after generation.  Delaying
-        // residency slot s of the FIRST generation by s * stagger de-phases the slots for the whole launch.
-        const int mode = p.stagger / 1000, units = p.stagger % 1000;
-        const int slot = mode == 0 ? (blockIdx.x >> 8) : mode == 1 ? ((blockIdx.x >> 3) & 3) : mode == 2 ? ((blockIdx.x >> 5) & 3) : ((blockIdx.x >> 6) & 3);
-        for (int i = 0; i < slot * units; ++i) __builtin_amdgcn_s_sleep(16);     // 1024 cycles each
-    }
     if (nkt > 0) issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         // tile kt has landed (every wave's pieces) and everybody is done reading the other stage
-        __syncthreads();
-        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        if (!(p.ablate & 4)) __syncthreads();
+        if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
         const float *sB = sA + G_TILE;
         mma_tile16<A_KMAJ, B_KMAJ>(sA, sB, arow, brow, half, acc);
@@ -241,6 +224,13 @@ sgemm_glds_kernel(const GemmArgs p) {
     e.C += coff;
     if (e.R) e.R += coff;
     if (e.aux) e.aux += coff;
+    if (WITH_COLSUM) {   // partial rows laid out [z0][tile row][wave row][z1][N]
+        const int nb1 = p.batch1;
+        e.cs += (((long)(z0 * p.tiles_m + tm) * 2) * nb1 + z1) * p.N;
+        e.cs_wm = (long)nb1 * p.N;
+        write_tile_buf<true>(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+        return;
+    }
     if (e.buf_ok) write_tile_buf(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
     else write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
@@ -248,12 +238,11 @@ sgemm_glds_kernel(const GemmArgs p) {
 inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 template <bool A_KMAJ, bool B_KMAJ>
-void launch(const GemmArgs &a, bool vec, int grid, hipStream_t stream) {
-    const bool dma_ok = vec && a.K % GK == 0 && a.k_per_split % GK == 0 &&
-                        (A_KMAJ ? (long)BM * a.lda + a.K : (long)a.k_per_split * a.lda + BM) * 4 < (1L << 31) &&
-                        (B_KMAJ ? (long)BN * a.ldb + a.K : (long)a.k_per_split * a.ldb + BN) * 4 < (1L << 31);
-    if (g_pipe == 2 && dma_ok)
-        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+void launch(const GemmArgs &a, bool vec, bool dma, int grid, hipStream_t stream) {
+    if (dma && a.e.cs)
+        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    else if (dma)
+        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(NTHREADS), 0, stream, a);
     else if (!vec)
         hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, false, 0>), dim3(grid), dim3(NTHREADS), 0, stream, a);
     else if (g_pipe == 1)
@@ -299,9 +288,8 @@ extern "C" int npm_conv_set_dma(int on);
 extern "C" int npm_set_tuning(int knob, int value) {
     switch (knob) {
         case NPM_TUNE_GEMM_PIPELINE: g_pipe = value; return NPM_OK;
-        case NPM_TUNE_GEMM_STAGGER: g_stagger = value; return NPM_OK;
         case NPM_TUNE_GEMM_GROUP_M: g_group_m = value > 0 ? value : 8; return NPM_OK;
-        case 99: g_ablate = value; return NPM_OK;
+        case NPM_TUNE_GEMM_ABLATE: g_ablate = value; return NPM_OK;
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
@@ -348,7 +336,6 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
                      (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) || fits(g->ldaux)) && fits(g->n);
     }
     a.group_m = g_group_m;
-    a.stagger = g_stagger;
     a.ablate = g_ablate;
 
     const long batch = (long)g->batch0 * g->batch1;
@@ -373,6 +360,8 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.splits = splits;
     a.k_per_split = splits > 1 ? kt_per_split * BK : (g->k > 0 ? nkt * BK : BK);
 
+    const bool want_colsum = g->colsum != nullptr;
+    if (want_colsum) splits = a.splits = 1, a.k_per_split = g->k > 0 ? nkt * BK : BK;
     npm::Scratch ws;
     if (splits > 1) {
         a.slab = batch * (long)g->m * g->n;
@@ -391,11 +380,36 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     const long grid = tiles * splits;
     NPM_ARG(grid < (1L << 31));
     hipStream_t stream = npm::ctx().stream;
-    if (a_kmaj && b_kmaj) launch<true, true>(a, vec, (int)grid, stream);
-    else if (a_kmaj && !b_kmaj) launch<true, false>(a, vec, (int)grid, stream);
-    else launch<false, false>(a, vec, (int)grid, stream);
+    // Column sums of the stored C: taken in the epilogue of the LDS-DMA kernel when it is eligible,
+    // otherwise by a separate pass over C (small / unaligned shapes).
+    const long a_span = (a_kmaj ? (long)BM * g->lda + g->k : (long)a.k_per_split * g->lda + BM) * 4;
+    const long b_span = (b_kmaj ? (long)BN * g->ldb + g->k : (long)a.k_per_split * g->ldb + BN) * 4;
+    const bool dma = g_pipe == 2 && vec && g->k % GK == 0 && a.k_per_split % GK == 0 &&
+                     a_span < (1L << 31) && b_span < (1L << 31);
+    const bool dma_path = dma && a.e.buf_ok;
+    npm::Scratch cs_part;
+    const long cs_rows = (long)g->batch0 * a.tiles_m * 2, cs_cols = (long)g->batch1 * g->n;
+    if (want_colsum && dma_path) {
+        int rc = cs_part.alloc(sizeof(float) * (size_t)cs_rows * cs_cols);
+        if (rc) return rc;
+        a.e.cs = (float *)cs_part.ptr;
+    }
+    if (a_kmaj && b_kmaj) launch<true, true>(a, vec, dma, (int)grid, stream);
+    else if (a_kmaj && !b_kmaj) launch<true, false>(a, vec, dma, (int)grid, stream);
+    else launch<false, false>(a, vec, dma, (int)grid, stream);
     NPM_CHECK_LAUNCH();
 
+    if (want_colsum) {
+        if (a.e.cs) return npm::colsum_launch(a.e.cs, g->colsum, cs_rows, cs_cols, cs_cols);
+        // fallback: one strided pass per z1 over the stored C (batches must be row-contiguous)
+        NPM_ARG(g->batch0 == 1 || g->stride_c0 == (int64_t)g->m * g->ldc);
+        for (int z1 = 0; z1 < g->batch1; ++z1) {
+            int rc = npm::colsum_launch(g->c + z1 * g->stride_c1, g->colsum + (long)z1 * g->n,
+                                        (long)g->m * g->batch0, g->n, g->ldc);
+            if (rc) return rc;
+        }
+        return NPM_OK;
+    }
     if (splits > 1) {
         ReduceArgs r{};
         r.ws = a.e.ws; r.slab = a.slab; r.splits = splits;

@@ -22,6 +22,9 @@ Context &ctx();
 void set_error(const char *fmt, ...);
 int fail(int code, const char *fmt, ...);
 
+// out[c] = sum_r x[r * ld + c], two-stage, fixed order (npm_rowops.hip)
+int colsum_launch(const float *x, float *out, long rows, long cols, long ld);
+
 // Pool-backed scratch for split-K slabs and reduction partials; released on scope exit.
 // Safe because every launch goes to the single compute stream (stream-ordered reuse).
 struct Scratch {

@@ -29,6 +29,8 @@ struct Epilogue {
     long ldaux;
     float *ws;               // split-K slabs (raw accumulators), pitch N
     int buf_ok;              // every extent (C, residual, aux, slab) < 2^31 bytes: buffer-instruction epilogue
+    float *cs;               // optional column-sum partials: one row of N per (tile row, wave row)
+    long cs_wm;              // elements between the partial rows of wave rows wm = 0 and 1
 };
 
 // Bijective XCD-contiguous remap: blocks b and b+8 share an XCD (and its L2), so give each
@@ -167,6 +169,7 @@ __device__ __forceinline__ void write_tile(const f32x16 (&acc)[2][2], const Epil
 // scalar (soffset) and rows >= M / columns >= N are dropped by the descriptor's range check
 // (out-of-range lanes carry an offset beyond num_records) -- no per-element address VALU,
 // no exec-mask juggling.  Requires every extent below 2^31 bytes (the host checks).
+template <bool WITH_COLSUM = false>
 __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const Epilogue &e, bool raw,
                                                int m0, int n0, int M, int N, int wm, int wn, int l32, int half) {
     constexpr int OOB = 0x7FFFFFFF;
@@ -187,7 +190,8 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
     const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)((relu_save || relu_mask) ? e.aux : cptr), 0,
                                                       (relu_save || relu_mask) ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
     int vc[2], vr[2], vx[2];
-    float bias[2];
+    float bias[2], csum[2] = {0.f, 0.f};
+    const bool want_cs = WITH_COLSUM && !raw && e.cs != nullptr;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l32;
@@ -214,8 +218,17 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
                 if (relu_mask) v = (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[j], sx, 0)) >= 0.f) ? v : 0.f;
                 if (relu) v = fmaxf(v, 0.f);
                 __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
+                if (WITH_COLSUM && want_cs && row + 4 * half < M) csum[j] += v;
             }
         }
+    if (WITH_COLSUM && want_cs) {   // this wave's 64 rows summed per column: rows live in the registers and the two lane halves
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const float total = csum[j] + __shfl_xor(csum[j], 32, 64);
+            const int col = n0 + wn * 64 + j * 32 + l32;
+            if (half == 0 && col < N) e.cs[wm * e.cs_wm + col] = total;
+        }
+    }
 }
 
 // Dense operand tile: global -> registers (4 float4 per thread), zero-filled outside

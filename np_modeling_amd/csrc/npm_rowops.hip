@@ -454,6 +454,10 @@ layernorm_bwd_dx_generic(const float *__restrict__ dz, const float *__restrict__
 
 }  // namespace
 
+namespace npm {
+int colsum_launch(const float *x, float *out, long rows, long cols, long ld) { return colsum_impl(x, out, rows, cols, ld); }
+}  // namespace npm
+
 // =====================================================================================
 extern "C" {
 

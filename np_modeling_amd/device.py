@@ -379,6 +379,10 @@ class Event:
 
 
 # ---- kernel wrappers -------------------------------------------------------------------------
+import os as _os
+
+FUSE_COLSUM = _os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switch (see gemm)
+
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its
     ALGORITHMIC work (flops for GEMMs, bytes for the HBM-bound kernels; DESIGN.md has the
@@ -441,8 +445,10 @@ class Mat:
 def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = False, trans_b: bool = False,
          batch: Tuple[int, int] = (1, 1), alpha: float = 1.0, bias: Optional[DeviceArray] = None,
          residual: Optional[Mat] = None, relu_save: Optional[Mat] = None, relu_mask: Optional[Mat] = None,
-         split_k: int = 0) -> None:
-    """C = epilogue(alpha * op(A) @ op(B)); see include/npm_hip.h ``npm_sgemm``."""
+         split_k: int = 0, colsum_out: Optional[DeviceArray] = None) -> None:
+    """C = epilogue(alpha * op(A) @ op(B)); see include/npm_hip.h ``npm_sgemm``.
+    ``colsum_out`` ([batch1, n]) receives the column sums of the stored C (a bias gradient
+    taken in the producing GEMM's epilogue instead of a separate pass over C)."""
     g = _C.npm_gemm()
     g.trans_a, g.trans_b = int(trans_a), int(trans_b)
     g.m, g.n, g.k = int(m), int(n), int(k)
@@ -466,11 +472,16 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
         g.aux, g.ldaux = relu_mask.ptr, relu_mask.ld
     g.epilogue = epi
     g.split_k = int(split_k)
+    fuse = colsum_out is not None and FUSE_COLSUM
+    g.colsum = colsum_out.ptr if fuse else None
     layout = 'TN' if trans_a else ('NT' if trans_b else 'NN')
     nb = batch[0] * batch[1]
     unique = 4.0 * nb * (m * k + k * n + m * n * (1 + (residual is not None) + (relu_save is not None) + (relu_mask is not None)))
     with _timed('sgemm_' + layout, flops=2.0 * m * n * k * nb, nbytes=unique):
         _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
+    if colsum_out is not None and not fuse:      # A/B switch: separate pass over the stored C
+        assert c.ld == n * batch[1] and (batch[1] == 1 or c.s1 == n), 'unfused colsum needs row-contiguous head slices'
+        colsum(DeviceArray([1], c._keep._buf, c.ptr), m * batch[0], n * batch[1], out=colsum_out)
 
 
 def colsum(x: DeviceArray, rows: int, cols: int, out: Optional[DeviceArray] = None) -> DeviceArray:

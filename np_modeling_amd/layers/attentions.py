@@ -147,9 +147,12 @@ class MultiHeadAttention(layer.StatefulLayer):
         dscores = D.empty([b, h, sq, skv])
         D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
                Mat(dscores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))             # dctx_h v_h^T
+        # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): column sums taken in
+        # the epilogues of the GEMMs that produce them
+        dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
         dv_ = D.empty([b, skv, h, dv])
         D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
-               Mat(dv_, h * dv, skv * h * dv, dv), trans_a=True, batch=(b, h))                    # P_h^T dctx_h
+               Mat(dv_, h * dv, skv * h * dv, dv), trans_a=True, batch=(b, h), colsum_out=dbv)    # P_h^T dctx_h
 
         # softmax backward with the 1/sqrt(dk) of attentions.py:155 folded in
         datt = D.softmax_bwd(scores, dscores, self._scale, out=dscores)
@@ -157,10 +160,10 @@ class MultiHeadAttention(layer.StatefulLayer):
         # Q K^T (attentions.py:161-162)
         dq = D.empty([b, sq, h, dk])
         D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, h * dk, skv * h * dk, dk),
-               Mat(dq, h * dk, sq * h * dk, dk), batch=(b, h))                                    # datt_h k_h
+               Mat(dq, h * dk, sq * h * dk, dk), batch=(b, h), colsum_out=dbq)                    # datt_h k_h
         dk_ = D.empty([b, skv, h, dk])
         D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, h * dk, sq * h * dk, dk),
-               Mat(dk_, h * dk, skv * h * dk, dk), trans_a=True, batch=(b, h))                    # datt_h^T q_h
+               Mat(dk_, h * dk, skv * h * dk, dk), trans_a=True, batch=(b, h), colsum_out=dbk)    # datt_h^T q_h
 
         # in-projections (attentions.py:167-188): dw = dproj^T x ; dx = dproj w
         dwq, dwk, dwv = scope.take(wq.shape), scope.take(wk.shape), scope.take(wv.shape)
@@ -184,11 +187,6 @@ class MultiHeadAttention(layer.StatefulLayer):
             assert value.shape == (b, skv, h * dv) and dv_.shape == (b, skv, h, dv)
             D.gemm(m_kv, fv, h * dv, Mat(dv_, h * dv), Mat(wv, fv), Mat(dvalue, fv))
             result = (dquery, dkey, dvalue)
-
-        dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
-        D.colsum(dq, m_q, h * dk, out=dbq)
-        D.colsum(dk_, m_kv, h * dk, out=dbk)
-        D.colsum(dv_, m_kv, h * dv, out=dbv)
 
         # update order of attentions.py:190-197
         for attribute, grad in (('_wq', dwq), ('_wk', dwk), ('_wv', dwv), ('_wo', dwo),

@@ -119,6 +119,7 @@ class HostSim:
     def npm_sgemm(self, gref):
         g = _deref(gref)
         self.calls.append('npm_sgemm')
+        sums = np.zeros((g.batch1, g.n), dtype=np.float64)
         for z0 in range(g.batch0):
             for z1 in range(g.batch1):
                 oa = 4 * (z0 * g.stride_a0 + z1 * g.stride_a1)
@@ -139,6 +140,9 @@ class HostSim:
                 if g.epilogue & 16:
                     v = np.maximum(v, 0.0)
                 _mat(g.c + oc, g.m, g.n, g.ldc)[:] = v
+                sums[z1] += _mat(g.c + oc, g.m, g.n, g.ldc).astype(np.float64).sum(axis=0)
+        if g.colsum:
+            _vec(g.colsum, g.batch1 * g.n)[:] = sums.ravel()
         return 0
 
     # ---- elementwise ------------------------------------------------------------------------

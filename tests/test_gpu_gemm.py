@@ -179,3 +179,24 @@ def test_ragged_tiles_do_not_write_outside_c(D, ta, tb, m, n, k):
     body = host[guard:guard + m * ldc].reshape(m, ldc)
     assert np.all(body[:, n:] == -777.0)
     assert_close(body[:, :n], _ref(a, b, ta, tb), tol=2e-6)
+
+
+@pytest.mark.parametrize('m,n,k,batch', [(256, 384, 64, (1, 1)), (100, 72, 48, (1, 1)), (130, 20, 33, (1, 1)),
+                                         (40, 16, 32, (3, 4)), (512, 128, 128, (2, 8))])
+def test_colsum_in_epilogue(D, m, n, k, batch):
+    """Bias gradients taken in the producing GEMM's epilogue: per head (z1) sums over z0 and rows,
+    of the STORED values (after the relu mask), on the DMA path and on the fallback path."""
+    rng = np.random.default_rng(m + n)
+    b0, b1 = batch
+    a = rng.standard_normal((b0, m, b1, k)).astype(np.float32)            # [B, S, H, D] head slices
+    w = rng.standard_normal((b0, k, b1, n)).astype(np.float32)
+    mask = rng.standard_normal((b0, m, b1, n)).astype(np.float32)
+    c = D.empty([b0, m, b1, n])
+    sums = D.full([b1, n], np.nan)
+    D.gemm(m, n, k, D.Mat(D.from_host(a), b1 * k, m * b1 * k, k), D.Mat(D.from_host(w), b1 * n, k * b1 * n, n),
+           D.Mat(c, b1 * n, m * b1 * n, n), batch=batch, relu_mask=D.Mat(D.from_host(mask), b1 * n),
+           colsum_out=sums)
+    want = np.einsum('zmhk,zkhn->zmhn', a.astype(np.float64), w.astype(np.float64))
+    want = np.where(mask >= 0, want, 0.0)
+    assert_close(c, want, tol=2e-6)
+    assert_close(sums, c.numpy().astype(np.float64).sum(axis=(0, 1)), tol=3e-6)
