@@ -111,6 +111,9 @@ enum {
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);
+/* Diagnostics: when buf != NULL every block of the LDS-DMA GEMM writes 8 words (hardware id, XCC id, s_memtime at
+ * start / first tile landed / loop end / after the epilogue stores) to buf[blockIdx*8 ..]; NULL switches it off. */
+int npm_debug_gemm_trace(long long *buf);
 
 /* ---- elementwise ---------------------------------------------------------- */
 int npm_relu_fwd(const float *x, float *y, size_t n);                      /* activations.py:15 */

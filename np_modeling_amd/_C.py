@@ -75,6 +75,7 @@ SIGNATURES = {
     'npm_event_elapsed_ms': [_P, _P, C.POINTER(_F)],
     'npm_sgemm': [C.POINTER(npm_gemm)],
     'npm_set_tuning': [C.c_int, C.c_int],
+    'npm_debug_gemm_trace': [_P],
     'npm_relu_fwd': [_P, _P, _SZ],
     'npm_relu_bwd': [_P, _P, _P, _SZ],
     'npm_add': [_P, _P, _P, _SZ],

@@ -38,6 +38,7 @@ struct GemmArgs {
     int batch1;
     int tiles_m, tiles_n, splits, k_per_split;
     int group_m;
+    long long *trace; // diagnostics: 8 words per block (hw id, xcc id, 4 s_memtime stamps) or null
     int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers
     long slab;       // split-K: batch * M * N
     Epilogue e;
@@ -46,6 +47,7 @@ struct GemmArgs {
 int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline where eligible
 int g_group_m = 8;
 int g_ablate = 0;
+long long *g_trace = nullptr;    // diagnostics: per-block timeline stamps (npm_debug_gemm_trace)
 int g_buf_epilogue = 1;
 
 // PIPE 0: one LDS buffer, two barriers per K tile (36 KB LDS, 3 blocks/CU).
@@ -145,7 +147,7 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // Needs 16-byte aligned operands and K (and every split) a multiple of 16.
 // ------------------------------------------------------------------------------------------
 template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM>
-__global__ void __launch_bounds__(NTHREADS, 4)
+__global__ void __launch_bounds__(NTHREADS, WITH_COLSUM ? 3 : 4)     // the column-sum epilogue needs ~20 more registers
 sgemm_glds_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
 
@@ -203,16 +205,36 @@ sgemm_glds_kernel(const GemmArgs p) {
     const int arow = wm * 64 + l32;
     const int brow = wn * 64 + l32;
 
+    long long t_start = 0, t_first = 0, t_loop = 0, r_start = 0;
+    if (p.trace) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
     if (nkt > 0) issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         // tile kt has landed (every wave's pieces) and everybody is done reading the other stage
         if (!(p.ablate & 4)) __syncthreads();
+        if (p.trace && kt == 0) t_first = __builtin_amdgcn_s_memtime();
         if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
         const float *sB = sA + G_TILE;
         mma_tile16<A_KMAJ, B_KMAJ>(sA, sB, arow, brow, half, acc);
     }
 
+    if (p.trace) t_loop = __builtin_amdgcn_s_memtime();
+    struct TraceOnExit {
+        long long *buf, t0, t1, t2, r0;
+        int tid;
+        __device__ ~TraceOnExit() {
+            if (buf && tid == 0) {
+                const long long t_issued = __builtin_amdgcn_s_memtime();
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores of this wave have left
+                long long *w = buf + (long)blockIdx.x * 8;
+                w[6] = t_issued;
+                w[7] = __builtin_amdgcn_s_memrealtime() - r0;      // 100 MHz ticks over the block's lifetime
+                w[0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);        // HW_REG_HW_ID
+                w[1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);       // HW_REG_XCC_ID
+                w[2] = t0; w[3] = t1; w[4] = t2; w[5] = __builtin_amdgcn_s_memtime();
+            }
+        }
+    } trace_guard{p.trace, t_start, t_first, t_loop, r_start, tid};
     Epilogue e = p.e;
     if (p.splits > 1) {
         e.ws += (long)split * p.slab + (long)z * p.M * p.N;
@@ -285,6 +307,8 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 
 extern "C" int npm_conv_set_dma(int on);
 
+extern "C" int npm_debug_gemm_trace(long long *buf) { g_trace = buf; return NPM_OK; }
+
 extern "C" int npm_set_tuning(int knob, int value) {
     switch (knob) {
         case NPM_TUNE_GEMM_PIPELINE: g_pipe = value; return NPM_OK;
@@ -337,6 +361,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     }
     a.group_m = g_group_m;
     a.ablate = g_ablate;
+    a.trace = g_trace;
 
     const long batch = (long)g->batch0 * g->batch1;
     const long tiles = (long)a.tiles_m * a.tiles_n * batch;

@@ -183,44 +183,81 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
     const bool relu_save = (flags & NPM_EPI_RELU_SAVE) != 0;
     const bool relu_mask = (flags & NPM_EPI_RELU_MASK) != 0;
     const bool relu = (flags & NPM_EPI_RELU) != 0;
-    const int ldr = has_res ? (int)e.ldr : 0;
-    const int ldx = (relu_save || relu_mask) ? (int)e.ldaux : 0;
-    const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R : cptr), 0,
-                                                      has_res ? (int)(((long)(M - 1) * ldr + N) * 4) : 0, 0x00020000);
-    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)((relu_save || relu_mask) ? e.aux : cptr), 0,
-                                                      (relu_save || relu_mask) ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
-    int vc[2], vr[2], vx[2];
-    float bias[2], csum[2] = {0.f, 0.f};
     const bool want_cs = WITH_COLSUM && !raw && e.cs != nullptr;
+    int vc[2];
+    float bias[2], csum[2] = {0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int col = n0 + wn * 64 + j * 32 + l32;
-        const bool ok = col < N;
-        vc[j] = ok ? (4 * half * ldc + col) * 4 : OOB;
-        vr[j] = ok ? (4 * half * ldr + col) * 4 : OOB;
-        vx[j] = ok ? (4 * half * ldx + col) * 4 : OOB;
-        bias[j] = (has_bias && ok) ? e.bias[col] : 0.f;
+        vc[j] = col < N ? (4 * half * ldc + col) * 4 : OOB;
+        bias[j] = (has_bias && col < N) ? e.bias[col] : 0.f;
     }
+    const int row0 = m0 + wm * 64;                     // wave-uniform
+
+    if (!has_res && !relu_save && !relu_mask) {
+        // Store-only epilogues (plain, bias, relu): 64 stores back to back, nothing to wait for.
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2);       // wave-uniform
-            const int sc = row * ldc * 4, sr = row * ldr * 4, sx = row * ldx * 4;
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                const int sc = row * ldc * 4;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                float v = alpha * acc[i][j][r] + bias[j];
-                if (has_res) v += __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vr[j], sr, 0));
-                if (relu_save) {
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rx, vx[j], sx, 0);
-                    v = fmaxf(v, 0.f);
+                for (int j = 0; j < 2; ++j) {
+                    float v = alpha * acc[i][j][r] + bias[j];
+                    if (relu) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
+                    if (WITH_COLSUM && want_cs && row + 4 * half < M) csum[j] += v;
                 }
-                if (relu_mask) v = (__uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx[j], sx, 0)) >= 0.f) ? v : 0.f;
-                if (relu) v = fmaxf(v, 0.f);
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
-                if (WITH_COLSUM && want_cs && row + 4 * half < M) csum[j] += v;
+            }
+    } else {
+        // Epilogues that READ (residual / ReLU mask) or write twice (ReLU with saved pre-activation):
+        // per 32x32 MFMA tile, issue its 16 loads together, wait once, then compute and store.
+        const int ldr = has_res ? (int)e.ldr : 0;
+        const int ldx = (relu_save || relu_mask) ? (int)e.ldaux : 0;
+        const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R : cptr), 0,
+                                                          has_res ? (int)(((long)(M - 1) * ldr + N) * 4) : 0, 0x00020000);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)((relu_save || relu_mask) ? e.aux : cptr), 0,
+                                                          (relu_save || relu_mask) ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l32;
+            const int vr = col < N ? (4 * half * ldr + col) * 4 : OOB;
+            const int vx = col < N ? (4 * half * ldx + col) * 4 : OOB;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                float res[16], msk[16];
+                if (has_res) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vr, row * ldr * 4, 0));
+                    }
+                }
+                if (relu_mask) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        msk[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, row * ldx * 4, 0));
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    float v = alpha * acc[i][j][r] + bias[j];
+                    if (has_res) v += res[r];
+                    if (relu_save) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rx, vx, row * ldx * 4, 0);
+                        v = fmaxf(v, 0.f);
+                    }
+                    if (relu_mask) v = msk[r] >= 0.f ? v : 0.f;
+                    if (relu) v = fmaxf(v, 0.f);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], row * ldc * 4, 0);
+                    if (WITH_COLSUM && want_cs && row + 4 * half < M) csum[j] += v;
+                }
             }
         }
+    }
     if (WITH_COLSUM && want_cs) {   // this wave's 64 rows summed per column: rows live in the registers and the two lane halves
 #pragma unroll
         for (int j = 0; j < 2; ++j) {

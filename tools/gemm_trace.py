@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""Per-block timeline of one LDS-DMA GEMM launch (npm_debug_gemm_trace): where blocks run (XCC / CU / SIMD),
+when they start, how long prologue / main loop / epilogue take, and which blocks share a CU."""
+import os, sys, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from np_modeling_amd import device as D, _C
+
+M, N, K = 131072, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+rng = np.random.default_rng(0)
+a = D.from_host(rng.standard_normal(M * K, dtype=np.float32))
+b = D.from_host(rng.standard_normal(K * N, dtype=np.float32))
+c = D.empty([M * N])
+grid = (M // 128) * (N // 128)
+buf = D._Buffer(grid * 64)
+fn = lambda: D.gemm(M, N, K, D.Mat(a, K), D.Mat(b, N), D.Mat(c, N))
+fn(); fn(); D.synchronize()
+_C.check(_C.lib().npm_debug_gemm_trace(buf.ptr))
+fn(); D.synchronize()
+_C.check(_C.lib().npm_debug_gemm_trace(None))
+host = np.empty(grid * 8, dtype=np.int64)
+_C.check(_C.lib().npm_d2h(host.ctypes.data, buf.ptr, host.nbytes))
+t = host.reshape(grid, 8)
+hw, xcc = t[:, 0], t[:, 1] & 0xF
+cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3; wave_slot = hw & 0xF
+t0 = t[:, 2].min()
+start, first, loop, end, issued = (t[:, i] - t0 for i in (2, 3, 4, 5, 6))
+print(f'K={K} blocks={grid}; clock ticks (s_memtime)')
+print('prologue (start->first tile landed): median %d  p90 %d' % (np.median(first - start), np.percentile(first - start, 90)))
+print('main loop: median %d  (per k-tile %d)' % (np.median(loop - first), np.median(loop - first) / (K // 16)))
+print('epilogue (loop end->stores drained): median %d p90 %d' % (np.median(end - loop), np.percentile(end - loop, 90)))
+print('epilogue issue only (loop end->last store issued): median %d p90 %d' % (np.median(issued - loop), np.percentile(issued - loop, 90)))
+real = t[:, 7]
+print('shader clock over block lifetimes: median %.2f GHz (p10 %.2f, p90 %.2f); lifetime median %.1f us' % (np.median((end - start) / real) * 0.1, np.percentile((end - start) / real, 10) * 0.1, np.percentile((end - start) / real, 90) * 0.1, np.median(real) / 100))
+print('block lifetime median %d ; kernel span %d' % (np.median(end - start), end.max()))
+key = list(zip(xcc, se, sh, cu))
+groups = collections.defaultdict(list)
+for i, k in enumerate(key):
+    groups[k].append(i)
+print('distinct (xcc,se,sh,cu):', len(groups), ' blocks per CU over the launch: min %d max %d' % (min(map(len, groups.values())), max(map(len, groups.values()))))
+# first-generation co-residents: for one CU list blocks with their start times
+for k in list(groups)[:3]:
+    ids = sorted(groups[k], key=lambda i: start[i])
+    print('CU', k, [(int(i), int(start[i]), int(end[i])) for i in ids[:8]])
+# are starts of co-resident blocks clustered?  for each CU sort by start; gaps between consecutive starts
+gaps = []
+for k, ids in groups.items():
+    s = np.sort(start[ids])
+    gaps.extend(np.diff(s))
+gaps = np.array(gaps)
+print('gap between consecutive block starts on a CU: p10 %d p50 %d p90 %d' % tuple(np.percentile(gaps, [10, 50, 90])))
