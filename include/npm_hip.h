@@ -77,7 +77,9 @@ enum {
     NPM_EPI_RESIDUAL = 2,    /* + residual[m,n] (may alias C: accumulate)  (transformer.py:39,53) */
     NPM_EPI_RELU_SAVE = 4,   /* aux[m,n] = v; C = max(v,0)                 (activations.py:14-15) */
     NPM_EPI_RELU_MASK = 8,   /* C = aux[m,n] >= 0 ? v : 0                  (activations.py:19) */
-    NPM_EPI_RELU = 16        /* C = max(v,0), pre-activation not kept (inference) */
+    NPM_EPI_RELU = 16,       /* C = max(v,0), pre-activation not kept (inference) */
+    NPM_EPI_SOFTMAX_BWD = 32 /* C = alpha * aux[m,n] * (acc - rowvec[m]): softmax backward with the row term
+                                sum_j dP_ij P_ij = dctx_i . ctx_i precomputed (activations.py:32-45, attentions.py:150-155) */
 };
 
 typedef struct npm_gemm {
@@ -93,6 +95,7 @@ typedef struct npm_gemm {
     const float *residual; int64_t ldr;  /* same batch strides as C */
     float *aux; int64_t ldaux;           /* same batch strides as C */
     int32_t split_k;                     /* 0 = choose automatically, 1 = never split */
+    const float *rowvec;                 /* [batch, m] per-row term of NPM_EPI_SOFTMAX_BWD */
     float *colsum;                       /* optional [batch1, n]: colsum[z1, j] = sum over z0 and rows of the stored C
                                             (the bias gradient np.sum(dy, axis=0), mlp.py:34 / attentions.py:190-197,
                                             taken in the producing GEMM's epilogue; fixed summation order) */
@@ -125,6 +128,8 @@ int npm_scale(const float *x, float *y, float alpha, size_t n);
 int npm_colsum(const float *x, float *out, int64_t rows, int64_t cols, int64_t ld); /* mlp.py:34 */
 
 /* ---- row kernels (one wavefront per row) ---------------------------------- */
+/* out[(b*H + h)*S + s] = sum_d a[b,s,h,d] * b[b,s,h,d]: the row term of the fused softmax backward */
+int npm_attn_rowdot(const float *a, const float *b, float *out, int64_t batch, int64_t seq, int64_t heads, int64_t dim);
 /* y = softmax(scale * x) over the last axis                    (activations.py:26-29, attentions.py:104) */
 int npm_softmax_fwd(const float *x, float *y, int64_t rows, int64_t n, float scale);
 /* dx = scale * y * (dy - sum(dy*y)): closed form of the Jacobian einsum (activations.py:32-45, attentions.py:155) */

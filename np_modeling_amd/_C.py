@@ -35,6 +35,7 @@ class npm_gemm(C.Structure):
         ('residual', C.c_void_p), ('ldr', C.c_int64),
         ('aux', C.c_void_p), ('ldaux', C.c_int64),
         ('split_k', C.c_int32),
+        ('rowvec', C.c_void_p),
         ('colsum', C.c_void_p),
     ]
 
@@ -49,7 +50,7 @@ class npm_conv2d(C.Structure):
     ]
 
 
-EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK = 1, 2, 4, 8
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK, EPI_RELU, EPI_SOFTMAX_BWD = 1, 2, 4, 8, 16, 32
 
 _P, _SZ, _I64, _I32, _F = C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_float
 
@@ -83,6 +84,7 @@ SIGNATURES = {
     'npm_axpy': [_P, _P, _F, _SZ],
     'npm_scale': [_P, _P, _F, _SZ],
     'npm_colsum': [_P, _P, _I64, _I64, _I64],
+    'npm_attn_rowdot': [_P, _P, _P, _I64, _I64, _I64, _I64],
     'npm_softmax_fwd': [_P, _P, _I64, _I64, _F],
     'npm_softmax_bwd': [_P, _P, _P, _I64, _I64, _F],
     'npm_layernorm_fwd': [_P, _P, _P, _F, _I64, _I64, _P, _P, _P],

@@ -133,6 +133,7 @@ sgemm_mfma_kernel(const GemmArgs p) {
     e.C += coff;
     if (e.R) e.R += coff;
     if (e.aux) e.aux += coff;
+    if (e.rowvec) e.rowvec += (long)z * p.M;
     write_tile(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
 
@@ -246,6 +247,7 @@ sgemm_glds_kernel(const GemmArgs p) {
     e.C += coff;
     if (e.R) e.R += coff;
     if (e.aux) e.aux += coff;
+    if (e.rowvec) e.rowvec += (long)z * p.M;
     if (WITH_COLSUM) {   // partial rows laid out [z0][tile row][wave row][z1][N]
         const int nb1 = p.batch1;
         e.cs += (((long)(z0 * p.tiles_m + tm) * 2) * nb1 + z1) * p.N;
@@ -331,6 +333,8 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     NPM_ARG(!(epi & NPM_EPI_RESIDUAL) || g->residual != nullptr);
     NPM_ARG(!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) || g->aux != nullptr);
     NPM_ARG(!((epi & NPM_EPI_RELU_SAVE) && (epi & NPM_EPI_RELU_MASK)));
+    NPM_ARG(!(epi & NPM_EPI_SOFTMAX_BWD) || (g->aux != nullptr && g->rowvec != nullptr &&
+            !(epi & (NPM_EPI_RESIDUAL | NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_BIAS))));
 
     const bool a_kmaj = g->trans_a == 0;   // A[M,K]: K contiguous
     const bool b_kmaj = g->trans_b != 0;   // B stored [N,K]: K contiguous
@@ -351,13 +355,14 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.e.bias = g->bias;
     a.e.R = (epi & NPM_EPI_RESIDUAL) ? g->residual : nullptr;
     a.e.ldr = g->ldr;
-    a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) ? g->aux : nullptr;
+    a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD)) ? g->aux : nullptr;
+    a.e.rowvec = (epi & NPM_EPI_SOFTMAX_BWD) ? g->rowvec : nullptr;
     a.e.ldaux = g->ldaux;
     {
         const long lim = 1L << 31;
         auto fits = [&](long ld) { return ((long)(g->m - 1) * ld + g->n) * 4 < lim; };
         a.e.buf_ok = g_buf_epilogue && fits(g->ldc) && (!(epi & NPM_EPI_RESIDUAL) || fits(g->ldr)) &&
-                     (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK)) || fits(g->ldaux)) && fits(g->n);
+                     (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD)) || fits(g->ldaux)) && fits(g->n);
     }
     a.group_m = g_group_m;
     a.ablate = g_ablate;
@@ -369,7 +374,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     // Split-K: only for the linear epilogues, when the grid cannot fill 256 CUs x 2-3 blocks.
     int splits = 1;
     const int nkt = (g->k + BK - 1) / BK;
-    const bool linear_epi = !(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_RELU));
+    const bool linear_epi = !(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_RELU | NPM_EPI_SOFTMAX_BWD));
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {

@@ -27,6 +27,7 @@ struct Epilogue {
     long ldr;
     float *aux;              // pre-activation out (RELU_SAVE) / mask in (RELU_MASK)
     long ldaux;
+    const float *rowvec;     // per-row term of NPM_EPI_SOFTMAX_BWD (already offset to this batch)
     float *ws;               // split-K slabs (raw accumulators), pitch N
     int buf_ok;              // every extent (C, residual, aux, slab) < 2^31 bytes: buffer-instruction epilogue
     float *cs;               // optional column-sum partials: one row of N per (tile row, wave row)
@@ -140,6 +141,7 @@ __device__ __forceinline__ void write_tile(const f32x16 (&acc)[2][2], const Epil
     const bool relu_save = (e.flags & NPM_EPI_RELU_SAVE) != 0;
     const bool relu_mask = (e.flags & NPM_EPI_RELU_MASK) != 0;
     const bool relu = (e.flags & NPM_EPI_RELU) != 0;
+    const bool sm_bwd = (e.flags & NPM_EPI_SOFTMAX_BWD) != 0;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -151,6 +153,7 @@ __device__ __forceinline__ void write_tile(const f32x16 (&acc)[2][2], const Epil
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < M && col < N) {
                     float v = e.alpha * acc[i][j][r] + bias;
+                    if (sm_bwd) v = e.alpha * e.aux[(long)row * e.ldaux + col] * (acc[i][j][r] - e.rowvec[row]);
                     if (has_res) v += e.R[(long)row * e.ldr + col];
                     if (relu_save) {
                         e.aux[(long)row * e.ldaux + col] = v;
@@ -183,6 +186,7 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
     const bool relu_save = (flags & NPM_EPI_RELU_SAVE) != 0;
     const bool relu_mask = (flags & NPM_EPI_RELU_MASK) != 0;
     const bool relu = (flags & NPM_EPI_RELU) != 0;
+    const bool sm_bwd = (flags & NPM_EPI_SOFTMAX_BWD) != 0;
     const bool want_cs = WITH_COLSUM && !raw && e.cs != nullptr;
     int vc[2];
     float bias[2], csum[2] = {0.f, 0.f};
@@ -194,7 +198,7 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
     }
     const int row0 = m0 + wm * 64;                     // wave-uniform
 
-    if (!has_res && !relu_save && !relu_mask) {
+    if (!has_res && !relu_save && !relu_mask && !sm_bwd) {
         // Store-only epilogues (plain, bias, relu): 64 stores back to back, nothing to wait for.
 #pragma unroll
         for (int i = 0; i < 2; ++i)
@@ -214,11 +218,13 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
         // Epilogues that READ (residual / ReLU mask) or write twice (ReLU with saved pre-activation):
         // per 32x32 MFMA tile, issue its 16 loads together, wait once, then compute and store.
         const int ldr = has_res ? (int)e.ldr : 0;
-        const int ldx = (relu_save || relu_mask) ? (int)e.ldaux : 0;
+        const bool use_aux = relu_save || relu_mask || sm_bwd;
+        const int ldx = use_aux ? (int)e.ldaux : 0;
+        const auto rv = __builtin_amdgcn_make_buffer_rsrc((void *)(sm_bwd ? e.rowvec : cptr), 0, sm_bwd ? M * 4 : 0, 0x00020000);
         const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R : cptr), 0,
                                                           has_res ? (int)(((long)(M - 1) * ldr + N) * 4) : 0, 0x00020000);
-        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)((relu_save || relu_mask) ? e.aux : cptr), 0,
-                                                          (relu_save || relu_mask) ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(use_aux ? e.aux : cptr), 0,
+                                                          use_aux ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + l32;
@@ -234,18 +240,26 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
                         res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vr, row * ldr * 4, 0));
                     }
                 }
-                if (relu_mask) {
+                if (relu_mask || sm_bwd) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                         msk[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, row * ldx * 4, 0));
                     }
                 }
+                if (sm_bwd) {   // res[] doubles as the per-row term (a residual is not combined with this mode)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                        res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, 16 * half, row * 4, 0));
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
                     float v = alpha * acc[i][j][r] + bias[j];
-                    if (has_res) v += res[r];
+                    if (sm_bwd) v = alpha * msk[r] * (acc[i][j][r] - res[r]);
+                    else if (has_res) v += res[r];
                     if (relu_save) {
                         __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rx, vx, row * ldx * 4, 0);
                         v = fmaxf(v, 0.f);

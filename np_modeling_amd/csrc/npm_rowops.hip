@@ -299,6 +299,34 @@ softmax_bwd_generic(const float *__restrict__ y, const float *__restrict__ dy, f
     for (long c = lane; c < n; c += WAVE) dx[row * n + c] = scale * yr[c] * (gr[c] - dot);
 }
 
+// out[(b*H + h)*S + s] = sum_d a[b,s,h,d] * b[b,s,h,d].  Half a wavefront (32 lanes x float4) covers a
+// 128-wide head; general dims loop.  Reads both tensors once (8 B/element).
+__global__ void __launch_bounds__(256)
+attn_rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out,
+                   long batch, long seq, long heads, long dim) {
+    const long rows = batch * seq * heads;
+    const int sub = threadIdx.x & 31;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;      // (b, s, h) flattened
+    if (row >= rows) return;
+    const float *pa = a + row * dim, *pb = b + row * dim;
+    float acc = 0.f;
+    if ((dim & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0) {
+        for (long c = sub * 4; c < dim; c += 128) {
+            const float4 x = *reinterpret_cast<const float4 *>(pa + c), y = *reinterpret_cast<const float4 *>(pb + c);
+            acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+        }
+    } else {
+        for (long c = sub; c < dim; c += 32) acc += pa[c] * pb[c];
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, WAVE);
+    if (sub == 0) {
+        const long h = row % heads, bs = row / heads;
+        const long s_ = bs % seq, b_ = bs / seq;
+        out[(b_ * heads + h) * seq + s_] = acc;
+    }
+}
+
 // ---- LayerNorm ---------------------------------------------------------------------
 template <int VPL>
 __global__ void __launch_bounds__(256)
@@ -520,6 +548,20 @@ int npm_colsum(const float *x, float *out, int64_t rows, int64_t cols, int64_t l
         else if (n <= 2048) hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
         else hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);         \
     } while (0)
+
+int npm_attn_rowdot(const float *a, const float *b, float *out, int64_t batch, int64_t seq, int64_t heads, int64_t dim) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(batch >= 0 && seq >= 0 && heads >= 1 && dim >= 1);
+    const long rows = batch * seq * heads;
+    if (rows == 0) return NPM_OK;
+    NPM_ARG(a && b && out);
+    const long blocks = (rows * 32 + 255) / 256;
+    NPM_ARG(blocks < (1L << 31));
+    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((int)blocks), dim3(256), 0, npm::ctx().stream, a, b, out,
+                       (long)batch, (long)seq, (long)heads, (long)dim);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
 
 int npm_softmax_fwd(const float *x, float *y, int64_t rows, int64_t n, float scale) {
     NPM_REQUIRE_INIT();

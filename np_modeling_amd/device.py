@@ -381,7 +381,8 @@ class Event:
 # ---- kernel wrappers -------------------------------------------------------------------------
 import os as _os
 
-FUSE_COLSUM = _os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switch (see gemm)
+FUSE_COLSUM = _os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switches (see gemm, attentions.py)
+FUSE_SOFTMAX_BWD = _os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
 
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its
@@ -445,10 +446,13 @@ class Mat:
 def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = False, trans_b: bool = False,
          batch: Tuple[int, int] = (1, 1), alpha: float = 1.0, bias: Optional[DeviceArray] = None,
          residual: Optional[Mat] = None, relu_save: Optional[Mat] = None, relu_mask: Optional[Mat] = None,
-         split_k: int = 0, colsum_out: Optional[DeviceArray] = None) -> None:
+         split_k: int = 0, colsum_out: Optional[DeviceArray] = None,
+         softmax_bwd: Optional[Tuple[Mat, DeviceArray]] = None) -> None:
     """C = epilogue(alpha * op(A) @ op(B)); see include/npm_hip.h ``npm_sgemm``.
     ``colsum_out`` ([batch1, n]) receives the column sums of the stored C (a bias gradient
-    taken in the producing GEMM's epilogue instead of a separate pass over C)."""
+    taken in the producing GEMM's epilogue instead of a separate pass over C).
+    ``softmax_bwd=(P, delta)``: C = alpha * P * (A @ B - delta[row]) -- the softmax backward with its
+    row term precomputed (:func:`attn_rowdot`), fused into the GEMM that produces dP."""
     g = _C.npm_gemm()
     g.trans_a, g.trans_b = int(trans_a), int(trans_b)
     g.m, g.n, g.k = int(m), int(n), int(k)
@@ -470,13 +474,18 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
     if relu_mask is not None:
         epi |= _C.EPI_RELU_MASK
         g.aux, g.ldaux = relu_mask.ptr, relu_mask.ld
+    if softmax_bwd is not None:
+        epi |= _C.EPI_SOFTMAX_BWD
+        g.aux, g.ldaux = softmax_bwd[0].ptr, softmax_bwd[0].ld
+        g.rowvec = softmax_bwd[1].ptr
     g.epilogue = epi
     g.split_k = int(split_k)
     fuse = colsum_out is not None and FUSE_COLSUM
     g.colsum = colsum_out.ptr if fuse else None
     layout = 'TN' if trans_a else ('NT' if trans_b else 'NN')
     nb = batch[0] * batch[1]
-    unique = 4.0 * nb * (m * k + k * n + m * n * (1 + (residual is not None) + (relu_save is not None) + (relu_mask is not None)))
+    unique = 4.0 * nb * (m * k + k * n + m * n * (1 + (residual is not None) + (relu_save is not None) +
+                                                  (relu_mask is not None) + (softmax_bwd is not None)))
     with _timed('sgemm_' + layout, flops=2.0 * m * n * k * nb, nbytes=unique):
         _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
     if colsum_out is not None and not fuse:      # A/B switch: separate pass over the stored C
@@ -534,6 +543,15 @@ def softmax_bwd(y: DeviceArray, dy: DeviceArray, scale: float = 1.0, out: Option
     out = empty(y.shape) if out is None else out
     with _timed('softmax_bwd', nbytes=12.0 * y.size):
         _C.check(_C.lib().npm_softmax_bwd(y.ptr, dy.ptr, out.ptr, rows, n, float(scale)), 'npm_softmax_bwd')
+    return out
+
+
+def attn_rowdot(a: DeviceArray, b: DeviceArray) -> DeviceArray:
+    """out[b, h, s] = sum_d a[b, s, h, d] * b[b, s, h, d]  (inputs [B, S, H, D])."""
+    bsz, seq, heads, dim = a.shape
+    out = empty([bsz, heads, seq])
+    with _timed('attn_rowdot', nbytes=8.0 * a.size):
+        _C.check(_C.lib().npm_attn_rowdot(a.ptr, b.ptr, out.ptr, bsz, seq, heads, dim), 'npm_attn_rowdot')
     return out
 
 

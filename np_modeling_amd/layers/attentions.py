@@ -144,18 +144,26 @@ class MultiHeadAttention(layer.StatefulLayer):
 
         # softmax @ V (attentions.py:146-148)
         assert v.shape == (b, skv, h, dv)
-        dscores = D.empty([b, h, sq, skv])
-        D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
-               Mat(dscores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))             # dctx_h v_h^T
+        # dP = dctx_h v_h^T followed by the softmax backward and the 1/sqrt(dk) of attentions.py:150-155.
+        # The row term sum_j dP_ij P_ij equals dctx_i . ctx_i (ctx = P v), so it is one cheap row-dot and the
+        # rest, datt = scale * P * (dP - row term), is elementwise: it rides the epilogue of the dP GEMM
+        # and dP itself never goes to memory.
+        datt = D.empty([b, h, sq, skv])
+        if D.FUSE_SOFTMAX_BWD:
+            delta = D.attn_rowdot(dctx, ctx)
+            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
+                   Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h), alpha=self._scale,
+                   softmax_bwd=(Mat(scores, skv), delta))
+        else:
+            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
+                   Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))            # dctx_h v_h^T
+            D.softmax_bwd(scores, datt, self._scale, out=datt)
         # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): column sums taken in
         # the epilogues of the GEMMs that produce them
         dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
         dv_ = D.empty([b, skv, h, dv])
         D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
                Mat(dv_, h * dv, skv * h * dv, dv), trans_a=True, batch=(b, h), colsum_out=dbv)    # P_h^T dctx_h
-
-        # softmax backward with the 1/sqrt(dk) of attentions.py:155 folded in
-        datt = D.softmax_bwd(scores, dscores, self._scale, out=dscores)
 
         # Q K^T (attentions.py:161-162)
         dq = D.empty([b, sq, h, dk])

@@ -128,6 +128,10 @@ class HostSim:
                 a = _mat(g.a + oa, g.k, g.m, g.lda).T if g.trans_a else _mat(g.a + oa, g.m, g.k, g.lda)
                 b = _mat(g.b + ob, g.n, g.k, g.ldb).T if g.trans_b else _mat(g.b + ob, g.k, g.n, g.ldb)
                 v = np.float64(g.alpha) * (a.astype(np.float64) @ b.astype(np.float64))
+                if g.epilogue & 32:
+                    z = z0 * g.batch1 + z1
+                    v = np.float64(g.alpha) * _mat(g.aux + oc, g.m, g.n, g.ldaux) * (
+                        a.astype(np.float64) @ b.astype(np.float64) - _vec(g.rowvec + 4 * z * g.m, g.m).astype(np.float64)[:, None])
                 if g.epilogue & 1:
                     v = v + _vec(g.bias, g.n).astype(np.float64)
                 if g.epilogue & 2:
@@ -175,6 +179,12 @@ class HostSim:
         return 0
 
     # ---- row kernels ---------------------------------------------------------------------------
+    def npm_attn_rowdot(self, a, b, out, batch, seq, heads, dim):
+        n = int(batch * seq * heads * dim)
+        prod = (_vec(a, n).astype(np.float64) * _vec(b, n)).reshape(batch, seq, heads, dim).sum(axis=-1)
+        _vec(out, batch * seq * heads)[:] = prod.transpose(0, 2, 1).ravel()
+        return 0
+
     def npm_softmax_fwd(self, x, y, rows, n, scale):
         _mat(y, rows, n, n)[:] = O.softmax_fwd(np.float64(scale) * _mat(x, rows, n, n).astype(np.float64))
         return 0

@@ -200,3 +200,28 @@ def test_colsum_in_epilogue(D, m, n, k, batch):
     want = np.where(mask >= 0, want, 0.0)
     assert_close(c, want, tol=2e-6)
     assert_close(sums, c.numpy().astype(np.float64).sum(axis=(0, 1)), tol=3e-6)
+
+
+@pytest.mark.parametrize('bsz,h,sq,skv,d', [(2, 4, 64, 128, 16), (3, 2, 40, 24, 12), (1, 8, 512, 512, 128), (2, 3, 33, 17, 5)])
+def test_softmax_backward_fused_into_the_dp_gemm(D, bsz, h, sq, skv, d):
+    """datt = scale * P * (dctx v^T - rowdot(dctx, ctx)) in one GEMM epilogue equals the reference's
+    Jacobian softmax backward of dP = dctx v^T (activations.py:32-45) scaled by 1/sqrt(dk)."""
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(bsz * 7 + sq)
+    logits = rng.standard_normal((bsz, h, sq, skv)) * 2
+    p = O.softmax_fwd(logits).astype(np.float32)
+    v = rng.standard_normal((bsz, skv, h, d)).astype(np.float32)
+    dctx = rng.standard_normal((bsz, sq, h, d)).astype(np.float32)
+    ctx = np.einsum('bhqk,bkhd->bqhd', p.astype(np.float64), v.astype(np.float64)).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    dp_, dv_, dd, dc = D.from_host(p), D.from_host(v), D.from_host(dctx), D.from_host(ctx)
+    delta = D.attn_rowdot(dd, dc)
+    want_delta = np.einsum('bqhd,bqhd->bhq', dctx.astype(np.float64), ctx.astype(np.float64))
+    assert_close(delta, want_delta, tol=3e-6)
+    datt = D.empty([bsz, h, sq, skv])
+    D.gemm(sq, skv, d, D.Mat(dd, h * d, sq * h * d, d), D.Mat(dv_, h * d, skv * h * d, d),
+           D.Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(bsz, h), alpha=scale,
+           softmax_bwd=(D.Mat(dp_, skv), delta))
+    dP = np.einsum('bqhd,bkhd->bhqk', dctx.astype(np.float64), v.astype(np.float64))
+    want = scale * O.softmax_bwd(p.astype(np.float64), dP, verbatim=(sq * skv * skv < 2e6))
+    assert_close(datt, want, tol=1e-5)
