@@ -212,31 +212,37 @@ conv_wgrad_kernel(const ConvArgs p) {
 constexpr int OOB_OFFSET = 0x7FFFFFFF;
 
 // forward / grad_x: requires C % 16 == 0 (a 16-deep K tile lies inside ONE tap), N % 4 == 0.
+// TALL = false: 128 x 128 block tile, waves 2 x 2.   TALL = true: 256 x 64 block tile, waves 4 x 1 --
+// for N <= 64 (grad_x of a layer with <= 64 input channels) a 128-wide tile would idle half the MFMAs.
+template <bool TALL>
 __global__ void __launch_bounds__(NTHREADS, 4)
 conv_fwd_glds_kernel(const ConvArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
+    constexpr int TM = TALL ? 256 : 128, TN = TALL ? 64 : 128;
+    constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
+    constexpr int A_PIECES = TM / 64, B_PIECES = TN / 64;     // 1 KiB DMA pieces per wave and tile
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+    const int wm = TALL ? wave : wave >> 1, wn = TALL ? 0 : wave & 1, l32 = lane & 31, half = lane >> 5;
 
     const int t = xcd_remap(blockIdx.x, gridDim.x);
     int tm, tn;
     tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TM, n0 = tn * TN;
     const int halo = p.pad * p.W + p.pad;                   // pixels a tap can reach back / forward
     const long first = (long)m0 - halo;                     // may be negative: never dereferenced
-    const long last = min((long)m0 + BM + halo, (long)p.M);
+    const long last = min((long)m0 + TM + halo, (long)p.M);
     const auto rsrcA = __builtin_amdgcn_make_buffer_rsrc((void *)(p.X + first * p.C), 0,
                                                          (int)((last - first) * p.C * 4), 0x00020000);
     const long b_left = ((long)(p.K - 1) * p.N + p.N - n0) * 4;
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.F + n0), 0, (int)min(b_left, 0x7FFFFFFEL), 0x00020000);
 
-    // this wave's two A pieces: rows 16 j + (lane >> 2), source chunk (lane & 3) ^ swizzle(row)
-    int rowv[2], ph[2], pw[2];
-    unsigned vbase[2];
+    // this wave's A pieces: rows 16 j + (lane >> 2), source chunk (lane & 3) ^ swizzle(row)
+    int rowv[A_PIECES], ph[A_PIECES], pw[A_PIECES];
+    unsigned vbase[A_PIECES];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 16 * (2 * wave + i) + (lane >> 2);
+    for (int i = 0; i < A_PIECES; ++i) {
+        const int row = 16 * (A_PIECES * wave + i) + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         const int m = m0 + row;
         rowv[i] = m;
@@ -244,37 +250,48 @@ conv_fwd_glds_kernel(const ConvArgs p) {
         ph[i] = (m / p.W) % p.H;
         vbase[i] = (unsigned)((row * p.C + c * 4) * 4);
     }
-    const unsigned vb0 = glds_voffset<false>(lane, 2 * wave, p.N), vb1 = glds_voffset<false>(lane, 2 * wave + 1, p.N);
+    // B pieces ([16 k][TN] rows of TN floats): a 1 KiB piece covers 1024 / (4 TN) k rows
+    constexpr int ROWS_PER_PIECE = 256 / TN, LANES_PER_ROW = TN / 4;
+    unsigned vb[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) {
+        const int krow = ROWS_PER_PIECE * (B_PIECES * wave + i) + lane / LANES_PER_ROW;
+        vb[i] = (unsigned)(krow * p.N * 4 + (lane % LANES_PER_ROW) * 16);
+    }
     const int nkt = p.K / GK;
 
     int c0 = 0, ti = 0, tj = 0;                             // tap / channel base of the NEXT tile to issue
-    auto issue = [&](int kt, int stage) {
-        float *sa = smem + stage * G_STAGE + (2 * wave) * 256;
-        float *sb = sa + G_TILE;
-        const int di = ti - p.pad, dj = tj - p.pad;
-        const unsigned soff = (unsigned)(((halo + di * p.W + dj) * p.C + c0) * 4);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const bool ok = rowv[i] < p.M && (unsigned)(ph[i] + di) < (unsigned)p.H && (unsigned)(pw[i] + dj) < (unsigned)p.W;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(sa + 256 * i), 16, ok ? vbase[i] : OOB_OFFSET, soff, 0, 0);
-        }
-        const unsigned kb = (unsigned)(kt * GK * p.N * 4);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)sb, 16, vb0, kb, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(sb + 256), 16, vb1, kb, 0, 0);
-        c0 += GK;
-        if (c0 == p.C) { c0 = 0; if (++tj == p.ks) { tj = 0; ++ti; } }
-    };
+    // (a macro, not a lambda: hipcc 7.2 fails to emit the host stub of this kernel template when a
+    // lambda with these builtins is called from it)
+#define NPM_CONV_ISSUE(KT, STG)                                                                              \
+    do {                                                                                                     \
+        float *sa = smem + (STG) * STAGE + (A_PIECES * wave) * 256;                                          \
+        float *sb = smem + (STG) * STAGE + A_TILE + (B_PIECES * wave) * 256;                                 \
+        const int di = ti - p.pad, dj = tj - p.pad;                                                          \
+        const unsigned soff = (unsigned)(((halo + di * p.W + dj) * p.C + c0) * 4);                           \
+        _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                               \
+            const bool ok = rowv[i] < p.M && (unsigned)(ph[i] + di) < (unsigned)p.H &&                       \
+                            (unsigned)(pw[i] + dj) < (unsigned)p.W;                                          \
+            lds_dma16(rsrcA, sa + 256 * i, ok ? vbase[i] : (unsigned)OOB_OFFSET, soff);                      \
+        }                                                                                                    \
+        const unsigned kb = (unsigned)((KT) * GK * p.N * 4);                                                 \
+        _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i)                                                 \
+            lds_dma16(rsrcB, sb + 256 * i, vb[i], kb);                                                       \
+        c0 += GK;                                                                                            \
+        if (c0 == p.C) { c0 = 0; if (++tj == p.ks) { tj = 0; ++ti; } }                                       \
+    } while (0)
 
     f32x16 acc[2][2];
     zero_acc(acc);
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
-    if (nkt > 0) issue(0, 0);
+    if (nkt > 0) NPM_CONV_ISSUE(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
-        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-        const float *sA = smem + (kt & 1) * G_STAGE;
-        mma_tile16<true, false>(sA, sA + G_TILE, arow, brow, half, acc);
+        if (kt + 1 < nkt) NPM_CONV_ISSUE(kt + 1, (kt + 1) & 1);
+        const float *sA = smem + (kt & 1) * STAGE;
+        mma_tile16<true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc);
     }
+#undef NPM_CONV_ISSUE
     if (p.e.buf_ok) write_tile_buf(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
     else write_tile(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
@@ -388,15 +405,21 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     a.tiles_n = (a.N + BN - 1) / BN;
     a.splits = 1; a.k_per_split = a.K; a.group_m = 8;
     a.e = e;
-    const long grid = (long)a.tiles_m * a.tiles_n;
-    NPM_ARG(grid < (1L << 31));
     const bool vec = c % 4 == 0 && n_out % 4 == 0 && aligned16(x) && aligned16(filt_kn);
     hipStream_t s = npm::ctx().stream;
     const long halo = (long)a.pad * w + a.pad;
     a.e.buf_ok = g_conv_dma && ((m - 1) * n_out + n_out) * 4 < (1L << 31);
-    const bool dma = g_conv_dma && vec && c % GK == 0 && (BM + 2 * halo) * c * 4 < (1L << 30) &&
+    const bool dma = g_conv_dma && vec && c % GK == 0 && (256 + 2 * halo) * c * 4 < (1L << 30) &&
                      (long)a.K * n_out * 4 < (1L << 31);
-    if (dma) hipLaunchKernelGGL(conv_fwd_glds_kernel, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    const bool tall = dma && n_out <= 64 && n_out % 16 == 0 && g_conv_dma != 2;
+    if (tall) {
+        a.tiles_m = (a.M + 255) / 256;
+        a.tiles_n = (a.N + 63) / 64;
+    }
+    const long grid = (long)a.tiles_m * a.tiles_n;
+    NPM_ARG(grid < (1L << 31));
+    if (tall) hipLaunchKernelGGL(conv_fwd_glds_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (dma) hipLaunchKernelGGL(conv_fwd_glds_kernel<false>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else if (vec) hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     NPM_CHECK_LAUNCH();

@@ -329,6 +329,13 @@ constexpr int G_STAGE = 2 * G_TILE;            // A + B
 
 typedef __attribute__((address_space(3))) void lds_void;
 
+// One LDS-DMA piece: 64 lanes x 16 bytes from (descriptor, per-lane voffset + scalar soffset) to 1 KiB of
+// LDS at `lds` (wave-uniform).  A plain function on purpose: called with value-dependent arguments straight
+// from a kernel TEMPLATE, hipcc 7.2 silently fails to emit that template's host-side launch stub.
+__device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float *lds, unsigned voffset, unsigned soffset) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)lds, 16, voffset, soffset, 0, 0);
+}
+
 template <bool KMAJ>
 __device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
     // byte offset of this lane's 16-byte chunk for wave-instruction j (0..7) of a tile, relative
@@ -343,27 +350,28 @@ __device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
     }
 }
 
-template <bool KMAJ>
+// MN_PITCH: floats per k row of an MN-major tile (the tile's width: 128, or 64 for the tall variant)
+template <bool KMAJ, int MN_PITCH = BM>
 __device__ __forceinline__ float4 read_frag16(const float *__restrict__ s, int row, int g, int half) {
     if (KMAJ) {
         const int c = (2 * g + half) ^ ((row >> 2) & 3);
         return *reinterpret_cast<const float4 *>(s + row * GK + c * 4);
     } else {
-        const float *p = s + (8 * g + 4 * half) * BM + row;
-        return make_float4(p[0], p[BM], p[2 * BM], p[3 * BM]);
+        const float *p = s + (8 * g + 4 * half) * MN_PITCH + row;
+        return make_float4(p[0], p[MN_PITCH], p[2 * MN_PITCH], p[3 * MN_PITCH]);
     }
 }
 
 // The 32 MFMAs of one 16-deep K tile for one wave.
-template <bool A_KMAJ, bool B_KMAJ>
+template <bool A_KMAJ, bool B_KMAJ, int B_PITCH = BM>
 __device__ __forceinline__ void mma_tile16(const float *__restrict__ sA, const float *__restrict__ sB,
                                            int arow, int brow, int half, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int g = 0; g < GK / 8; ++g) {
         const float4 a0 = read_frag16<A_KMAJ>(sA, arow, g, half);
         const float4 a1 = read_frag16<A_KMAJ>(sA, arow + 32, g, half);
-        const float4 b0 = read_frag16<B_KMAJ>(sB, brow, g, half);
-        const float4 b1 = read_frag16<B_KMAJ>(sB, brow + 32, g, half);
+        const float4 b0 = read_frag16<B_KMAJ, B_PITCH>(sB, brow, g, half);
+        const float4 b1 = read_frag16<B_KMAJ, B_PITCH>(sB, brow + 32, g, half);
         const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
         const float bv[2][4] = {{b0.x, b0.y, b0.z, b0.w}, {b1.x, b1.y, b1.z, b1.w}};
 #pragma unroll

@@ -43,7 +43,9 @@ def test_conv_golden(npm, name, shape, channels, k):
 @pytest.mark.parametrize('n,h,w,c0,c1,k', [(1, 1, 1, 1, 1, 1), (2, 5, 4, 3, 5, 3), (1, 7, 9, 6, 10, 5),
                                            (64, 32, 16, 32, 16, 3),       # reference conv_test.py shape
                                            (2, 16, 16, 64, 128, 3),       # C3 channel counts, small image
-                                           (3, 6, 6, 20, 132, 1), (1, 3, 40, 8, 8, 7)])
+                                           (3, 6, 6, 20, 132, 1), (1, 3, 40, 8, 8, 7),
+                                           (2, 20, 12, 64, 128, 3),       # grad_x takes the tall 256x64 tile (N = 64)
+                                           (1, 9, 9, 16, 48, 5), (3, 7, 5, 32, 16, 3)])
 def test_conv_kernels_vs_oracle(npm, n, h, w, c0, c1, k):
     from np_modeling_amd import _C, device as D
     lib = _C.lib()
