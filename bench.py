@@ -58,13 +58,18 @@ def make_params(rng, feat, heads, hidden):
 
 
 def bind(enc, p):
+    """Overwrite the lazily initialised parameters IN PLACE (same device storage, same layout)."""
     att = enc._self_attention
     for n in ('wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo'):
-        setattr(att, '_' + n, p['att_' + n])
-    enc._norm1._gamma, enc._norm1._beta = p['n1_gamma'], p['n1_beta']
-    enc._norm2._gamma, enc._norm2._beta = p['n2_gamma'], p['n2_beta']
-    enc._dense1._linear._w, enc._dense1._linear._b = p['d1_w'], p['d1_b']
-    enc._dense2._w, enc._dense2._b = p['d2_w'], p['d2_b']
+        getattr(att, '_' + n).set(p['att_' + n])
+    enc._norm1._gamma.set(p['n1_gamma'])
+    enc._norm1._beta.set(p['n1_beta'])
+    enc._norm2._gamma.set(p['n2_gamma'])
+    enc._norm2._beta.set(p['n2_beta'])
+    enc._dense1._linear._w.set(p['d1_w'])
+    enc._dense1._linear._b.set(p['d1_b'])
+    enc._dense2._w.set(p['d2_w'])
+    enc._dense2._b.set(p['d2_b'])
 
 
 def cpu_baseline(args, params):

@@ -383,6 +383,7 @@ import os as _os
 
 FUSE_COLSUM = _os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switches (see gemm, attentions.py)
 FUSE_SOFTMAX_BWD = _os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
+PACK_QKV = _os.environ.get('NPM_PACK_QKV', '1') != '0'
 
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its

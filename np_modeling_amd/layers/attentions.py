@@ -53,14 +53,40 @@ class MultiHeadAttention(layer.StatefulLayer):
         self._key_dim = dk = key.shape[2] // h
         assert value.shape[2] % h == 0
         self._value_dim = dv = value.shape[2] // h
-        self._wq = self._new_param([h, dk, h * dk])
-        self._wk = self._new_param([h, dk, h * dk])
-        self._wv = self._new_param([h, dv, h * dv])
-        self._wo = self._new_param([h * dk, h, dv])
-        self._bq = self._new_param([h, dk])
-        self._bk = self._new_param([h, dk])
-        self._bv = self._new_param([h, dv])
-        self._bo = self._new_param([h * dk])
+        # Draw order wq, wk, wv, wo, bq, bk, bv, bo (attentions.py:46-65).  When the three in-projections
+        # have one shape they are stored back to back (views of one [3, H, D, F] buffer), so that
+        # self-attention can run them as ONE GEMM; rebinding any of them (weight binders do) just
+        # falls back to three GEMMs.
+        draws = [self._initializer([h, dk, h * dk]), self._initializer([h, dk, h * dk]),
+                 self._initializer([h, dv, h * dv])]
+        wo = self._initializer([h * dk, h, dv])
+        bias_draws = [self._initializer([h, dk]), self._initializer([h, dk]), self._initializer([h, dv])]
+        bo = self._initializer([h * dk])
+        if dk == dv:
+            packed_w, packed_b = D.empty([3, h, dk, h * dk]), D.empty([3, h, dk])
+            for i, (name, bname) in enumerate((('_wq', '_bq'), ('_wk', '_bk'), ('_wv', '_bv'))):
+                setattr(self, name, packed_w.flat_view(i * h * dk * h * dk, [h, dk, h * dk]).set(draws[i]))
+                setattr(self, bname, packed_b.flat_view(i * h * dk, [h, dk]).set(bias_draws[i]))
+        else:
+            self._wq, self._wk, self._wv = (D.as_device(a) for a in draws)
+            self._bq, self._bk, self._bv = (D.as_device(a) for a in bias_draws)
+        self._wo = D.as_device(wo)
+        self._bo = D.as_device(bo)
+
+    def _params_adjacent(self) -> bool:
+        """wq/wk/wv (and bq/bk/bv) still back to back in memory?  Checked at EVERY use: parameters may be
+        rebound between a forward and its backward (weight binders, tests)."""
+        w = [self._param(p) for p in ('_wq', '_wk', '_wv')]
+        b = [self._param(p) for p in ('_bq', '_bk', '_bv')]
+        return (w[0].shape == w[1].shape == w[2].shape and
+                w[1].ptr == w[0].ptr + w[0].nbytes and w[2].ptr == w[1].ptr + w[1].nbytes and
+                b[1].ptr == b[0].ptr + b[0].nbytes and b[2].ptr == b[1].ptr + b[1].nbytes)
+
+    def _packed_qkv(self, query, key, value) -> bool:
+        """Self-attention with the in-projection parameters adjacent in memory: one GEMM makes q, k and v."""
+        if not (query is key and key is value) or self._key_dim != self._value_dim or not D.PACK_QKV:
+            return False
+        return self._params_adjacent()
 
     def _numel(self) -> int:
         return sum(self._param(p).size for p in _PARAMS) + 4 * len(_PARAMS)
@@ -84,18 +110,30 @@ class MultiHeadAttention(layer.StatefulLayer):
         bq, bk, bv, bo = (self._param(p) for p in ('_bq', '_bk', '_bv', '_bo'))
         self._query, self._key, self._value, self._mask = query, key, value, None
 
-        # in-projections: [rows, F] x w[H*D, F]^T + b
-        q = D.empty([b, sq, h, dk])
-        k = D.empty([b, skv, h, dk])
-        v = D.empty([b, skv, h, dv])
-        D.gemm(b * sq, h * dk, f, Mat(query, f), Mat(wq, f), Mat(q, h * dk), trans_b=True, bias=bq)
-        D.gemm(b * skv, h * dk, f, Mat(key, f), Mat(wk, f), Mat(k, h * dk), trans_b=True, bias=bk)
-        D.gemm(b * skv, h * dv, fv, Mat(value, fv), Mat(wv, fv), Mat(v, h * dv), trans_b=True, bias=bv)
+        # in-projections: [rows, F] x w[H*D, F]^T + b.  q/k/v are [B, S, H, D] head slices addressed through
+        # (array, element offset, row pitch): separate tensors, or thirds of one packed [B, S, 3, H, D].
+        packed = self._packed_qkv(query, key, value)
+        self._packed = packed
+        if packed:
+            qkv = D.empty([b, sq, 3, h, dk])
+            D.gemm(b * sq, 3 * f, f, Mat(query, f), Mat(wq, f), Mat(qkv, 3 * f), trans_b=True, bias=bq)
+            pitch = 3 * f
+            q, k, v = qkv, qkv.flat_view(f, [1]), qkv.flat_view(2 * f, [1])
+        else:
+            pitch = None
+            q = D.empty([b, sq, h, dk])
+            k = D.empty([b, skv, h, dk])
+            v = D.empty([b, skv, h, dv])
+            D.gemm(b * sq, h * dk, f, Mat(query, f), Mat(wq, f), Mat(q, h * dk), trans_b=True, bias=bq)
+            D.gemm(b * skv, h * dk, f, Mat(key, f), Mat(wk, f), Mat(k, h * dk), trans_b=True, bias=bk)
+            D.gemm(b * skv, h * dv, fv, Mat(value, fv), Mat(wv, fv), Mat(v, h * dv), trans_b=True, bias=bv)
         self._q, self._k, self._v = q, k, v
+        pq, pk, pv = pitch or h * dk, pitch or h * dk, pitch or h * dv       # row pitches of q, k, v
+        self._pitches = (pq, pk, pv)
 
         # attention[b, h] = q_h k_h^T ; scores = softmax(attention / sqrt(dk))
         scores = D.empty([b, h, sq, skv])
-        D.gemm(sq, skv, dk, Mat(q, h * dk, sq * h * dk, dk), Mat(k, h * dk, skv * h * dk, dk),
+        D.gemm(sq, skv, dk, Mat(q, pq, sq * pq, dk), Mat(k, pk, skv * pk, dk),
                Mat(scores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))
         self._scale = 1.0 / math.sqrt(dk)
         D.softmax_fwd(scores, self._scale, out=scores)
@@ -104,7 +142,7 @@ class MultiHeadAttention(layer.StatefulLayer):
 
         # context[b, :, h, :] = scores[b, h] v_h      -> [B, Sq, H, Dv]
         ctx = D.empty([b, sq, h, dv])
-        D.gemm(sq, dv, skv, Mat(scores, skv, h * sq * skv, sq * skv), Mat(v, h * dv, skv * h * dv, dv),
+        D.gemm(sq, dv, skv, Mat(scores, skv, h * sq * skv, sq * skv), Mat(v, pv, skv * pv, dv),
                Mat(ctx, h * dv, sq * h * dv, dv), batch=(b, h))
         self._context = ctx
 
@@ -143,7 +181,8 @@ class MultiHeadAttention(layer.StatefulLayer):
         D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))                    # dy wo
 
         # softmax @ V (attentions.py:146-148)
-        assert v.shape == (b, skv, h, dv)
+        packed = self._packed
+        pq, pk, pv = self._pitches
         # dP = dctx_h v_h^T followed by the softmax backward and the 1/sqrt(dk) of attentions.py:150-155.
         # The row term sum_j dP_ij P_ij equals dctx_i . ctx_i (ctx = P v), so it is one cheap row-dot and the
         # rest, datt = scale * P * (dP - row term), is elementwise: it rides the epilogue of the dP GEMM
@@ -151,49 +190,61 @@ class MultiHeadAttention(layer.StatefulLayer):
         datt = D.empty([b, h, sq, skv])
         if D.FUSE_SOFTMAX_BWD:
             delta = D.attn_rowdot(dctx, ctx)
-            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
+            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
                    Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h), alpha=self._scale,
                    softmax_bwd=(Mat(scores, skv), delta))
         else:
-            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, h * dv, skv * h * dv, dv),
+            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
                    Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))            # dctx_h v_h^T
             D.softmax_bwd(scores, datt, self._scale, out=datt)
         # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): column sums taken in
         # the epilogues of the GEMMs that produce them
-        dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
-        dv_ = D.empty([b, skv, h, dv])
+        if packed:      # gradients of the packed parameters and of q/k/v live in packed buffers too
+            dw_all, db_all = scope.take([3, h, dk, f]), scope.take([3, h, dk])
+            dwq, dwk, dwv = (dw_all.flat_view(i * h * dk * f, [h, dk, f]) for i in range(3))
+            dbq, dbk, dbv = (db_all.flat_view(i * h * dk, [h, dk]) for i in range(3))
+            dqkv = D.empty([b, sq, 3, h, dk])
+            dq, dk_, dv_ = dqkv, dqkv.flat_view(f, [1]), dqkv.flat_view(2 * f, [1])
+            gq = gk = gv = 3 * f
+        else:
+            dwq, dwk, dwv = scope.take(wq.shape), scope.take(wk.shape), scope.take(wv.shape)
+            dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
+            dq, dk_, dv_ = D.empty([b, sq, h, dk]), D.empty([b, skv, h, dk]), D.empty([b, skv, h, dv])
+            gq, gk, gv = h * dk, h * dk, h * dv
         D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
-               Mat(dv_, h * dv, skv * h * dv, dv), trans_a=True, batch=(b, h), colsum_out=dbv)    # P_h^T dctx_h
+               Mat(dv_, gv, skv * gv, dv), trans_a=True, batch=(b, h), colsum_out=dbv)            # P_h^T dctx_h
 
         # Q K^T (attentions.py:161-162)
-        dq = D.empty([b, sq, h, dk])
-        D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, h * dk, skv * h * dk, dk),
-               Mat(dq, h * dk, sq * h * dk, dk), batch=(b, h), colsum_out=dbq)                    # datt_h k_h
-        dk_ = D.empty([b, skv, h, dk])
-        D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, h * dk, sq * h * dk, dk),
-               Mat(dk_, h * dk, skv * h * dk, dk), trans_a=True, batch=(b, h), colsum_out=dbk)    # datt_h^T q_h
+        D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, pk, skv * pk, dk),
+               Mat(dq, gq, sq * gq, dk), batch=(b, h), colsum_out=dbq)                            # datt_h k_h
+        D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, pq, sq * pq, dk),
+               Mat(dk_, gk, skv * gk, dk), trans_a=True, batch=(b, h), colsum_out=dbk)            # datt_h^T q_h
 
         # in-projections (attentions.py:167-188): dw = dproj^T x ; dx = dproj w
-        dwq, dwk, dwv = scope.take(wq.shape), scope.take(wk.shape), scope.take(wv.shape)
-        D.gemm(h * dk, f, m_q, Mat(dq, h * dk), Mat(query, f), Mat(dwq, f), trans_a=True)
-        D.gemm(h * dk, f, m_kv, Mat(dk_, h * dk), Mat(key, f), Mat(dwk, f), trans_a=True)
-        D.gemm(h * dv, fv, m_kv, Mat(dv_, h * dv), Mat(value, fv), Mat(dwv, fv), trans_a=True)
-
+        if packed:
+            D.gemm(3 * f, f, m_q, Mat(dqkv, 3 * f), Mat(query, f), Mat(dw_all, f), trans_a=True)
+        else:
+            D.gemm(h * dk, f, m_q, Mat(dq, gq), Mat(query, f), Mat(dwq, f), trans_a=True)
+            D.gemm(h * dk, f, m_kv, Mat(dk_, gk), Mat(key, f), Mat(dwk, f), trans_a=True)
+            D.gemm(h * dv, fv, m_kv, Mat(dv_, gv), Mat(value, fv), Mat(dwv, fv), trans_a=True)
         if sum_inputs:
             assert query is key and key is value
             total = D.empty([b, sq, f])
-            D.gemm(m_q, f, h * dk, Mat(dq, h * dk), Mat(wq, f), Mat(total, f),
-                   residual=None if residual is None else Mat(residual, f))
-            D.gemm(m_kv, f, h * dk, Mat(dk_, h * dk), Mat(wk, f), Mat(total, f), residual=Mat(total, f))
-            D.gemm(m_kv, fv, h * dv, Mat(dv_, h * dv), Mat(wv, fv), Mat(total, fv), residual=Mat(total, fv))
+            res = None if residual is None else Mat(residual, f)
+            if packed and self._params_adjacent():      # dq wq + dk wk + dv wv: one contraction over the packed 3F axis
+                D.gemm(m_q, f, 3 * f, Mat(dqkv, 3 * f), Mat(wq, f), Mat(total, f), residual=res)
+            else:
+                D.gemm(m_q, f, h * dk, Mat(dq, gq), Mat(wq, f), Mat(total, f), residual=res)
+                D.gemm(m_kv, f, h * dk, Mat(dk_, gk), Mat(wk, f), Mat(total, f), residual=Mat(total, f))
+                D.gemm(m_kv, fv, h * dv, Mat(dv_, gv), Mat(wv, fv), Mat(total, fv), residual=Mat(total, fv))
             result = total
         else:
             assert residual is None
             dquery, dkey, dvalue = D.empty([b, sq, f]), D.empty([b, skv, f]), D.empty([b, skv, fv])
-            D.gemm(m_q, f, h * dk, Mat(dq, h * dk), Mat(wq, f), Mat(dquery, f))
-            D.gemm(m_kv, f, h * dk, Mat(dk_, h * dk), Mat(wk, f), Mat(dkey, f))
-            assert value.shape == (b, skv, h * dv) and dv_.shape == (b, skv, h, dv)
-            D.gemm(m_kv, fv, h * dv, Mat(dv_, h * dv), Mat(wv, fv), Mat(dvalue, fv))
+            D.gemm(m_q, f, h * dk, Mat(dq, gq), Mat(wq, f), Mat(dquery, f))
+            D.gemm(m_kv, f, h * dk, Mat(dk_, gk), Mat(wk, f), Mat(dkey, f))
+            assert value.shape == (b, skv, h * dv)
+            D.gemm(m_kv, fv, h * dv, Mat(dv_, gv), Mat(wv, fv), Mat(dvalue, fv))
             result = (dquery, dkey, dvalue)
 
         # update order of attentions.py:190-197

@@ -84,6 +84,28 @@ def test_encoder_composition_on_simulator(npm, name):
     assert_close(enc._norm1._gamma, g['n1_gamma__1'], tol=1e-5)
 
 
+def test_weights_rebound_between_forward_and_backward(npm):
+    """The packed q/k/v projection must not assume the parameters are still adjacent in the backward:
+    bench.py (and weight binders) rebind them after the first forward."""
+    from oracle import np_oracle as O
+    np.random.seed(0)
+    layer = npm.layers.MultiHeadAttention(num_heads=2)
+    x = rand([2, 6, 8])
+    layer(x)
+    assert layer._packed
+    names = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+    p = {n: np.asarray(getattr(layer, '_' + n)).copy() for n in names}
+    _, cache = O.mha_fwd({k: v.astype(np.float64) for k, v in p.items()}, x.astype(np.float64))
+    for n in names:                                  # rebind AFTER the forward: separate allocations
+        setattr(layer, '_' + n, p[n].copy())
+    dy = rand([2, 6, 8])
+    dq, dk, dv = layer(dy, backprop=True, learning_rate=0.1)
+    (wq_, wk_, wv_), grads = O.mha_bwd({k: v.astype(np.float64) for k, v in p.items()}, cache, dy.astype(np.float64))
+    assert_close(np.asarray(dq) + np.asarray(dk) + np.asarray(dv), wq_ + wk_ + wv_, tol=1e-5)
+    for n in names:
+        assert_close(getattr(layer, '_' + n), p[n] - 0.1 * grads[n], tol=1e-5, what=n)
+
+
 def test_conv_layer_on_simulator(npm):
     g = load_golden('conv_k3')
     np.random.seed(0)
