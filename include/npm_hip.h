@@ -111,6 +111,7 @@ enum {
     NPM_TUNE_GEMM_GROUP_M = 2,
     NPM_TUNE_GEMM_BUF_EPILOGUE = 3,
     NPM_TUNE_CONV_DMA = 4,
+    NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never, 1 always, 2 (default) NN/NT */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);

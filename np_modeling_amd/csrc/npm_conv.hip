@@ -408,7 +408,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     const bool vec = c % 4 == 0 && n_out % 4 == 0 && aligned16(x) && aligned16(filt_kn);
     hipStream_t s = npm::ctx().stream;
     const long halo = (long)a.pad * w + a.pad;
-    a.e.buf_ok = g_conv_dma && ((m - 1) * n_out + n_out) * 4 < (1L << 31);
+    a.e.buf_ok = g_conv_dma && (256L * n_out + n_out) * 4 < (1L << 31);
     const bool dma = g_conv_dma && vec && c % GK == 0 && (256 + 2 * halo) * c * 4 < (1L << 30) &&
                      (long)a.K * n_out * 4 < (1L << 31);
     const bool tall = dma && n_out <= 64 && n_out % 16 == 0 && g_conv_dma != 2;
@@ -505,7 +505,7 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     hipStream_t s = npm::ctx().stream;
     const int grid = (int)(tiles * splits);
     const long halo = (long)a.pad * w + a.pad;
-    a.e.buf_ok = g_conv_dma && (long)a.M * a.N * 4 < (1L << 31);
+    a.e.buf_ok = g_conv_dma && (256L * a.N + a.N) * 4 < (1L << 31);
     const bool dma = g_conv_dma && vec && pixels % GK == 0 && a.k_per_split % GK == 0 &&
                      ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) &&
                      (long)a.k_per_split * c_out * 4 < (1L << 30);

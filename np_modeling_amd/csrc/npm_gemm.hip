@@ -39,6 +39,7 @@ struct GemmArgs {
     int tiles_m, tiles_n, splits, k_per_split;
     int group_m;
     long long *trace; // diagnostics: 8 words per block (hw id, xcc id, 4 s_memtime stamps) or null
+    int wide;        // 128 x 256 block tile (2 x 4 waves) instead of 128 x 128
     int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers
     long slab;       // split-K: batch * M * N
     Epilogue e;
@@ -47,6 +48,7 @@ struct GemmArgs {
 int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline where eligible
 int g_group_m = 8;
 int g_ablate = 0;
+int g_wide_tile = 0;               // NPM_TUNE_GEMM_WIDE_TILE: 128 x 256 tile where n % 256 == 0: 0 never, 1 always, 2 NN/NT, 3 NT only
 long long *g_trace = nullptr;    // diagnostics: per-block timeline stamps (npm_debug_gemm_trace)
 int g_buf_epilogue = 1;
 
@@ -147,15 +149,22 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // c' ^ ((r >> 2) & 3); reads apply the same XOR (conflict-free ds_read_b128).
 // Needs 16-byte aligned operands and K (and every split) a multiple of 16.
 // ------------------------------------------------------------------------------------------
-template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM>
-__global__ void __launch_bounds__(NTHREADS, WITH_COLSUM ? 3 : 4)     // the column-sum epilogue needs ~20 more registers
+// WM x WN wavefronts per block, each owning 64 x 64 of the (64 WM) x (64 WN) block tile.
+//   2 x 2 (256 threads, 4 blocks/CU): the default.   2 x 4 (512 threads, 2 blocks/CU): 128 x 256 tile --
+//   each activation panel is re-read by half as many column tiles (less L2-miss traffic per FLOP).
+template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2>
+__global__ void __launch_bounds__(64 * WM * WN, (WITH_COLSUM ? 12 : 16) / (WM * WN))   // 16 (12) waves per CU
 sgemm_glds_kernel(const GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
+    constexpr int A_PW = 4 / WN, B_PW = 4 / WM;          // 1 KiB DMA pieces per wave and K tile
+    static_assert(A_PW * WM * WN * 16 == TM && B_PW * WM * WN * 16 == TN, "pieces must tile the operands");
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l32 = lane & 31, half = lane >> 5;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -166,7 +175,7 @@ sgemm_glds_kernel(const GemmArgs p) {
     const int z = rest / p.splits;
     int tm, tn;
     tile_coords(t, p.tiles_m, p.tiles_n, p.group_m, tm, tn);
-    const int m0 = tm * BM, n0 = tn * BN;
+    const int m0 = tm * TM, n0 = tn * TN;
     const int z0 = z / p.batch1, z1 = z - z0 * p.batch1;
 
     const int kbeg = split * p.k_per_split;
@@ -185,20 +194,23 @@ sgemm_glds_kernel(const GemmArgs p) {
                                                          (int)min(a_left, 0xFFFFFFFFL), 0x00020000);
     const auto rsrcB = __builtin_amdgcn_make_buffer_rsrc((void *)(p.B + b_batch + b_panel), 0,
                                                          (int)min(b_left, 0xFFFFFFFFL), 0x00020000);
-    // each wave issues DMA pieces j = 2*wave, 2*wave+1 of both operand tiles
-    const unsigned va0 = glds_voffset<A_KMAJ>(lane, 2 * wave, p.lda), va1 = glds_voffset<A_KMAJ>(lane, 2 * wave + 1, p.lda);
-    const unsigned vb0 = glds_voffset<B_KMAJ>(lane, 2 * wave, p.ldb), vb1 = glds_voffset<B_KMAJ>(lane, 2 * wave + 1, p.ldb);
+    // this wave's DMA pieces of both operand tiles
+    unsigned va[A_PW], vb[B_PW];
+#pragma unroll
+    for (int i = 0; i < A_PW; ++i) va[i] = glds_voffset<A_KMAJ, TM>(lane, A_PW * wave + i, p.lda);
+#pragma unroll
+    for (int i = 0; i < B_PW; ++i) vb[i] = glds_voffset<B_KMAJ, TN>(lane, B_PW * wave + i, p.ldb);
     const unsigned a_kstep = A_KMAJ ? GK * 4u : (unsigned)(GK * p.lda * 4);
     const unsigned b_kstep = B_KMAJ ? GK * 4u : (unsigned)(GK * p.ldb * 4);
 
     auto issue = [&](int kt, int stage) {
-        float *sa = smem + stage * G_STAGE + (2 * wave) * 256;        // 1 KiB per piece
-        float *sb = sa + G_TILE;
+        float *sa = smem + stage * STAGE + (A_PW * wave) * 256;        // 1 KiB per piece
+        float *sb = smem + stage * STAGE + A_TILE + (B_PW * wave) * 256;
         const unsigned ka = kt * a_kstep, kb = kt * b_kstep;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)sa, 16, va0, ka, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void *)(sa + 256), 16, va1, ka, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)sb, 16, vb0, kb, 0, 0);
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void *)(sb + 256), 16, vb1, kb, 0, 0);
+#pragma unroll
+        for (int i = 0; i < A_PW; ++i) lds_dma16(rsrcA, sa + 256 * i, va[i], ka);
+#pragma unroll
+        for (int i = 0; i < B_PW; ++i) lds_dma16(rsrcB, sb + 256 * i, vb[i], kb);
     };
 
     f32x16 acc[2][2];
@@ -214,9 +226,9 @@ sgemm_glds_kernel(const GemmArgs p) {
         if (!(p.ablate & 4)) __syncthreads();
         if (p.trace && kt == 0) t_first = __builtin_amdgcn_s_memtime();
         if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
-        const float *sA = smem + (kt & 1) * G_STAGE;
-        const float *sB = sA + G_TILE;
-        mma_tile16<A_KMAJ, B_KMAJ>(sA, sB, arow, brow, half, acc);
+        const float *sA = smem + (kt & 1) * STAGE;
+        const float *sB = sA + A_TILE;
+        mma_tile16<A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc);
     }
 
     if (p.trace) t_loop = __builtin_amdgcn_s_memtime();
@@ -263,7 +275,9 @@ inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 template <bool A_KMAJ, bool B_KMAJ>
 void launch(const GemmArgs &a, bool vec, bool dma, int grid, hipStream_t stream) {
-    if (dma && a.e.cs)
+    if (dma && a.wide)
+        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false, 2, 4>), dim3(grid), dim3(512), 0, stream, a);
+    else if (dma && a.e.cs)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
     else if (dma)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(NTHREADS), 0, stream, a);
@@ -316,6 +330,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_PIPELINE: g_pipe = value; return NPM_OK;
         case NPM_TUNE_GEMM_GROUP_M: g_group_m = value > 0 ? value : 8; return NPM_OK;
         case NPM_TUNE_GEMM_ABLATE: g_ablate = value; return NPM_OK;
+        case NPM_TUNE_GEMM_WIDE_TILE: g_wide_tile = value; return NPM_OK;
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
@@ -348,8 +363,19 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.sC0 = g->stride_c0; a.sC1 = g->stride_c1;
     a.M = g->m; a.N = g->n; a.K = g->k;
     a.batch1 = g->batch1;
+    // float4 / DMA staging needs 16-B aligned rows in both operands.
+    auto strides_ok = [](long s0, long s1) { return (s0 % 4 == 0) && (s1 % 4 == 0); };
+    bool vec = aligned16(g->a) && aligned16(g->b) && g->lda % 4 == 0 && g->ldb % 4 == 0 &&
+               strides_ok(g->stride_a0, g->stride_a1) && strides_ok(g->stride_b0, g->stride_b1);
+    vec = vec && (a_kmaj ? g->k % 4 == 0 : g->m % 4 == 0);
+    vec = vec && (b_kmaj ? g->k % 4 == 0 : g->n % 4 == 0);
+    const bool want_colsum = g->colsum != nullptr;
+    // 128 x 256 tile: only where it divides N and the LDS-DMA kernel will run (spans re-checked below)
+    const int tile_n = ((g_wide_tile == 1 || (g_wide_tile == 2 && a_kmaj) || (g_wide_tile == 3 && a_kmaj && b_kmaj)) && g_pipe == 2 && vec && g->k % GK == 0 && g->n % 256 == 0 && !want_colsum &&
+                        (long)256 * g->ldb * 4 < (1L << 30)) ? 256 : BN;
+    a.wide = tile_n == 256;
     a.tiles_m = (g->m + BM - 1) / BM;
-    a.tiles_n = (g->n + BN - 1) / BN;
+    a.tiles_n = (g->n + tile_n - 1) / tile_n;
     a.e.alpha = g->alpha;
     a.e.flags = epi;
     a.e.bias = g->bias;
@@ -359,8 +385,8 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.e.rowvec = (epi & NPM_EPI_SOFTMAX_BWD) ? g->rowvec : nullptr;
     a.e.ldaux = g->ldaux;
     {
-        const long lim = 1L << 31;
-        auto fits = [&](long ld) { return ((long)(g->m - 1) * ld + g->n) * 4 < lim; };
+        // the buffer epilogue addresses one block (<= 256 rows) at a time: its row pitches must keep that below 2^31
+        auto fits = [&](long ld) { return (256L * ld + g->n) * 4 < (1L << 31); };
         a.e.buf_ok = g_buf_epilogue && fits(g->ldc) && (!(epi & NPM_EPI_RESIDUAL) || fits(g->ldr)) &&
                      (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD)) || fits(g->ldaux)) && fits(g->n);
     }
@@ -390,7 +416,6 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.splits = splits;
     a.k_per_split = splits > 1 ? kt_per_split * BK : (g->k > 0 ? nkt * BK : BK);
 
-    const bool want_colsum = g->colsum != nullptr;
     if (want_colsum) splits = a.splits = 1, a.k_per_split = g->k > 0 ? nkt * BK : BK;
     npm::Scratch ws;
     if (splits > 1) {
@@ -400,22 +425,17 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
         a.e.ws = (float *)ws.ptr;
     }
 
-    // float4 staging needs 16-B aligned rows in both operands.
-    auto strides_ok = [](long s0, long s1) { return (s0 % 4 == 0) && (s1 % 4 == 0); };
-    bool vec = aligned16(g->a) && aligned16(g->b) && g->lda % 4 == 0 && g->ldb % 4 == 0 &&
-               strides_ok(g->stride_a0, g->stride_a1) && strides_ok(g->stride_b0, g->stride_b1);
-    vec = vec && (a_kmaj ? g->k % 4 == 0 : g->m % 4 == 0);
-    vec = vec && (b_kmaj ? g->k % 4 == 0 : g->n % 4 == 0);
-
     const long grid = tiles * splits;
     NPM_ARG(grid < (1L << 31));
     hipStream_t stream = npm::ctx().stream;
     // Column sums of the stored C: taken in the epilogue of the LDS-DMA kernel when it is eligible,
     // otherwise by a separate pass over C (small / unaligned shapes).
     const long a_span = (a_kmaj ? (long)BM * g->lda + g->k : (long)a.k_per_split * g->lda + BM) * 4;
-    const long b_span = (b_kmaj ? (long)BN * g->ldb + g->k : (long)a.k_per_split * g->ldb + BN) * 4;
+    const long b_span = (b_kmaj ? (long)tile_n * g->ldb + g->k : (long)a.k_per_split * g->ldb + tile_n) * 4;
     const bool dma = g_pipe == 2 && vec && g->k % GK == 0 && a.k_per_split % GK == 0 &&
                      a_span < (1L << 31) && b_span < (1L << 31);
+    if (a.wide && !(dma && a.e.buf_ok))
+        return npm::fail(NPM_E_UNSUPPORTED, "npm_sgemm: operand spans too large for the 128x256 tile (disable NPM_TUNE_GEMM_WIDE_TILE)");
     const bool dma_path = dma && a.e.buf_ok;
     npm::Scratch cs_part;
     const long cs_rows = (long)g->batch0 * a.tiles_m * 2, cs_cols = (long)g->batch1 * g->n;

@@ -176,11 +176,14 @@ template <bool WITH_COLSUM = false>
 __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const Epilogue &e, bool raw,
                                                int m0, int n0, int M, int N, int wm, int wn, int l32, int half) {
     constexpr int OOB = 0x7FFFFFFF;
-    float *cptr = raw ? e.ws : e.C;
+    // Descriptors are rebased to this block's first row, so offsets stay below 256 rows x pitch whatever the
+    // size of C (a [131072, 4096] fp32 output is exactly 2^31 bytes); rows_here bounds the range check.
     const int ldc = raw ? N : (int)e.ldc;
+    const int rows_here = min(M - m0, 256);
+    float *cptr = (raw ? e.ws : e.C) + (long)m0 * ldc;
     const int flags = raw ? 0 : e.flags;
     const float alpha = raw ? 1.f : e.alpha;
-    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void *)cptr, 0, (int)(((long)(M - 1) * ldc + N) * 4), 0x00020000);
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void *)cptr, 0, (int)(((long)(rows_here - 1) * ldc + N) * 4), 0x00020000);
     const bool has_bias = (flags & NPM_EPI_BIAS) != 0;
     const bool has_res = (flags & NPM_EPI_RESIDUAL) != 0;
     const bool relu_save = (flags & NPM_EPI_RELU_SAVE) != 0;
@@ -196,7 +199,7 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
         vc[j] = col < N ? (4 * half * ldc + col) * 4 : OOB;
         bias[j] = (has_bias && col < N) ? e.bias[col] : 0.f;
     }
-    const int row0 = m0 + wm * 64;                     // wave-uniform
+    const int row0 = wm * 64;                          // wave-uniform, relative to the block's first row
 
     if (!has_res && !relu_save && !relu_mask && !sm_bwd) {
         // Store-only epilogues (plain, bias, relu): 64 stores back to back, nothing to wait for.
@@ -211,7 +214,7 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
                     float v = alpha * acc[i][j][r] + bias[j];
                     if (relu) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
-                    if (WITH_COLSUM && want_cs && row + 4 * half < M) csum[j] += v;
+                    if (WITH_COLSUM && want_cs && row + 4 * half < rows_here) csum[j] += v;
                 }
             }
     } else {
@@ -220,11 +223,11 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
         const int ldr = has_res ? (int)e.ldr : 0;
         const bool use_aux = relu_save || relu_mask || sm_bwd;
         const int ldx = use_aux ? (int)e.ldaux : 0;
-        const auto rv = __builtin_amdgcn_make_buffer_rsrc((void *)(sm_bwd ? e.rowvec : cptr), 0, sm_bwd ? M * 4 : 0, 0x00020000);
-        const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R : cptr), 0,
-                                                          has_res ? (int)(((long)(M - 1) * ldr + N) * 4) : 0, 0x00020000);
-        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(use_aux ? e.aux : cptr), 0,
-                                                          use_aux ? (int)(((long)(M - 1) * ldx + N) * 4) : 0, 0x00020000);
+        const auto rv = __builtin_amdgcn_make_buffer_rsrc((void *)(sm_bwd ? e.rowvec + m0 : cptr), 0, sm_bwd ? rows_here * 4 : 0, 0x00020000);
+        const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R + (long)m0 * ldr : cptr), 0,
+                                                          has_res ? (int)(((long)(rows_here - 1) * ldr + N) * 4) : 0, 0x00020000);
+        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(use_aux ? e.aux + (long)m0 * ldx : cptr), 0,
+                                                          use_aux ? (int)(((long)(rows_here - 1) * ldx + N) * 4) : 0, 0x00020000);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + l32;
@@ -267,7 +270,7 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
                     if (relu_mask) v = msk[r] >= 0.f ? v : 0.f;
                     if (relu) v = fmaxf(v, 0.f);
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], row * ldc * 4, 0);
-                    if (WITH_COLSUM && want_cs && row + 4 * half < M) csum[j] += v;
+                    if (WITH_COLSUM && want_cs && row + 4 * half < rows_here) csum[j] += v;
                 }
             }
         }
@@ -336,17 +339,19 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float *ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)lds, 16, voffset, soffset, 0, 0);
 }
 
-template <bool KMAJ>
+// WIDTH: rows (K-major) / floats per k row (MN-major) of the operand tile: 128, or 256 for the wide tile.
+template <bool KMAJ, int WIDTH = BM>
 __device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
-    // byte offset of this lane's 16-byte chunk for wave-instruction j (0..7) of a tile, relative
+    // byte offset of this lane's 16-byte chunk for DMA piece j (0 .. WIDTH/16 - 1) of a tile, relative
     // to the tile's first row (K-major) / first k row (MN-major), K offset excluded
     if (KMAJ) {
         const int row = 16 * j + (lane >> 2);
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         return (unsigned)(row * ld * 4 + c * 16);
     } else {
-        const int krow = 2 * j + (lane >> 5);
-        return (unsigned)(krow * ld * 4 + (lane & 31) * 16);
+        constexpr int LANES_PER_ROW = WIDTH / 4, ROWS_PER_PIECE = 64 / LANES_PER_ROW;
+        const int krow = ROWS_PER_PIECE * j + lane / LANES_PER_ROW;
+        return (unsigned)(krow * ld * 4 + (lane % LANES_PER_ROW) * 16);
     }
 }
 
@@ -363,13 +368,13 @@ __device__ __forceinline__ float4 read_frag16(const float *__restrict__ s, int r
 }
 
 // The 32 MFMAs of one 16-deep K tile for one wave.
-template <bool A_KMAJ, bool B_KMAJ, int B_PITCH = BM>
+template <bool A_KMAJ, bool B_KMAJ, int B_PITCH = BM, int A_PITCH = BM>
 __device__ __forceinline__ void mma_tile16(const float *__restrict__ sA, const float *__restrict__ sB,
                                            int arow, int brow, int half, f32x16 (&acc)[2][2]) {
 #pragma unroll
     for (int g = 0; g < GK / 8; ++g) {
-        const float4 a0 = read_frag16<A_KMAJ>(sA, arow, g, half);
-        const float4 a1 = read_frag16<A_KMAJ>(sA, arow + 32, g, half);
+        const float4 a0 = read_frag16<A_KMAJ, A_PITCH>(sA, arow, g, half);
+        const float4 a1 = read_frag16<A_KMAJ, A_PITCH>(sA, arow + 32, g, half);
         const float4 b0 = read_frag16<B_KMAJ, B_PITCH>(sB, brow, g, half);
         const float4 b1 = read_frag16<B_KMAJ, B_PITCH>(sB, brow + 32, g, half);
         const float av[2][4] = {{a0.x, a0.y, a0.z, a0.w}, {a1.x, a1.y, a1.z, a1.w}};
