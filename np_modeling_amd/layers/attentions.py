@@ -227,6 +227,9 @@ class MultiHeadAttention(layer.StatefulLayer):
             D.gemm(h * dk, f, m_q, Mat(dq, gq), Mat(query, f), Mat(dwq, f), trans_a=True)
             D.gemm(h * dk, f, m_kv, Mat(dk_, gk), Mat(key, f), Mat(dwk, f), trans_a=True)
             D.gemm(h * dv, fv, m_kv, Mat(dv_, gv), Mat(value, fv), Mat(dwv, fv), trans_a=True)
+        # every parameter gradient of this layer now exists: start exchanging them (data parallel) under
+        # the remaining input-gradient GEMMs
+        scope.flush()
         if sum_inputs:
             assert query is key and key is value
             total = D.empty([b, sq, f])
