@@ -149,7 +149,14 @@ def set_communicator(comm: Optional[Communicator], reduce: str = 'avg') -> None:
 
 
 def communicator() -> Communicator:
-    return _COMM if _COMM is not None else Communicator()
+    """The active transport.  Under a one-process-per-GPU launcher (WORLD_SIZE > 1 in the environment) the
+    RCCL group is joined on first use, so a training script written for one GPU synchronises its gradients
+    without changes; NPM_AUTO_PARALLEL=0 disables that."""
+    if _COMM is None:
+        if int(os.environ.get('WORLD_SIZE', '1')) > 1 and os.environ.get('NPM_AUTO_PARALLEL', '1') != '0':
+            return init()
+        return Communicator()
+    return _COMM
 
 
 def world_size() -> int:
@@ -177,6 +184,36 @@ def shard(array, axis: int = 0):
     index = [slice(None)] * array.ndim
     index[axis] = slice(r * per, (r + 1) * per)
     return np.ascontiguousarray(array[tuple(index)])
+
+
+def parameters(layer) -> List['D.DeviceArray']:
+    """Every device-resident parameter of a (possibly composite) layer, in a deterministic order."""
+    from np_modeling_amd.layers.layer import Layer
+    names = ('_w', '_b', '_wq', '_wk', '_wv', '_wo', '_bq', '_bk', '_bv', '_bo', '_gamma', '_beta')
+    found, stack, seen = [], [layer], set()
+    while stack:
+        obj = stack.pop()
+        if id(obj) in seen:
+            continue
+        seen.add(id(obj))
+        for key in sorted(vars(obj)):
+            value = getattr(obj, key)
+            if key in names and value is not None:
+                found.append(obj._param(key))
+            elif isinstance(value, Layer):
+                stack.append(value)
+    return found
+
+
+def sync_parameters(layers: Sequence, root: int = 0) -> None:
+    """Broadcast rank ``root``'s parameters to every rank (call once after the first forward, when ranks
+    did not seed NumPy identically).  No-op for one process."""
+    comm = communicator()
+    if not comm.active:
+        return
+    for layer in layers:
+        for param in parameters(layer):
+            comm.broadcast(param.reshape(-1), root)
 
 
 # --------------------------------------------------------------------------------------------

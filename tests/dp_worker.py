@@ -14,6 +14,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
+os.environ['NPM_AUTO_PARALLEL'] = '0'          # this worker installs a gloo transport explicitly
+
 import torch                      # noqa: E402
 import torch.distributed as dist  # noqa: E402
 

@@ -52,3 +52,19 @@ def test_encoder_step_with_exchange_path_active(comm):
 
     for a, b in zip(run(False), run(True)):
         np.testing.assert_array_equal(a, b)
+
+
+def test_sync_parameters_walks_composites(comm):
+    import np_modeling_amd as npm
+    from np_modeling_amd import parallel
+    parallel.set_communicator(comm)
+    np.random.seed(1)
+    enc = npm.layers.TransformerEncoder(num_heads=2, hidden_units=16, norm_first=False)
+    enc(np.random.normal(size=[2, 4, 8]).astype(np.float32))
+    params = parallel.parameters(enc)
+    assert len(params) == 16 and sum(p.size for p in params) == 4 * 64 + 3 * 8 + 8 + 4 * 8 + 8 * 16 + 16 + 16 * 8 + 8
+    before = [np.asarray(p).copy() for p in params]
+    parallel.sync_parameters([enc])                 # one rank: broadcast is the identity
+    for a, p in zip(before, params):
+        np.testing.assert_array_equal(a, np.asarray(p))
+    parallel.set_communicator(None)
