@@ -20,6 +20,7 @@ from __future__ import annotations
 import ctypes as C
 import math
 import numbers
+import os
 from typing import Optional, Sequence, Tuple, Union
 
 import numpy as np
@@ -379,11 +380,9 @@ class Event:
 
 
 # ---- kernel wrappers -------------------------------------------------------------------------
-import os as _os
-
-FUSE_COLSUM = _os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switches (see gemm, attentions.py)
-FUSE_SOFTMAX_BWD = _os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
-PACK_QKV = _os.environ.get('NPM_PACK_QKV', '1') != '0'
+FUSE_COLSUM = os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switches (see gemm, attentions.py)
+FUSE_SOFTMAX_BWD = os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
+PACK_QKV = os.environ.get('NPM_PACK_QKV', '1') != '0'
 
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its

@@ -14,7 +14,7 @@ from __future__ import annotations
 
 from np_modeling_amd import device as D
 from np_modeling_amd import parallel
-from np_modeling_amd.layers import activations, attentions, layer, mlp, normalizations
+from np_modeling_amd.layers import attentions, layer, mlp, normalizations
 
 
 def _identity_dropout(*dropouts) -> bool:

@@ -25,7 +25,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-from typing import Callable, List, Optional, Sequence, Tuple
+from typing import List, Optional, Sequence, Tuple
 
 from np_modeling_amd import _C
 from np_modeling_amd import device as D
