@@ -136,8 +136,24 @@ def _bind(cdll, signatures, special):
     return cdll
 
 
+def _build_if_missing(path: str) -> None:
+    """The shared libraries are build artefacts (git-ignored).  If they are absent and the ROCm
+    compiler is present, build them in tree once -- still no CPU fallback: no compiler, no library."""
+    if os.path.exists(path) or os.environ.get('NPM_NO_AUTOBUILD') == '1':
+        return
+    import shutil
+    import subprocess
+    hipcc = os.environ.get('HIPCC') or shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
+    if not os.path.exists(hipcc):
+        return
+    subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j4', f'HIPCC={hipcc}'], check=False,
+                   stdout=subprocess.DEVNULL)
+
+
 def load_library(path: str = LIB_PATH):
     """dlopen libnpm_hip.so and declare every prototype of include/npm_hip.h."""
+    if path == LIB_PATH:
+        _build_if_missing(path)
     if not os.path.exists(path):
         raise NpmError(
             f'{path} is missing: build the HIP library first '
@@ -147,6 +163,8 @@ def load_library(path: str = LIB_PATH):
 
 
 def load_comm_library(path: str = RCCL_LIB_PATH):
+    if path == RCCL_LIB_PATH:
+        _build_if_missing(path)
     if not os.path.exists(path):
         raise NpmError(f'{path} is missing: build it with make -C np_modeling_amd/csrc')
     return _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), COMM_SIGNATURES, _COMM_SPECIAL)
