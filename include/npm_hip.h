@@ -112,6 +112,8 @@ enum {
     NPM_TUNE_GEMM_BUF_EPILOGUE = 3,
     NPM_TUNE_CONV_DMA = 4,
     NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never, 1 always, 2 (default) NN/NT */
+    NPM_TUNE_LN_BWD_BLOCKS = 6,      /* blocks per CU of the LayerNorm backward grid (default 4) */
+    NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);

@@ -333,6 +333,8 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_WIDE_TILE: g_wide_tile = value; return NPM_OK;
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
+        case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
+        case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }
 }

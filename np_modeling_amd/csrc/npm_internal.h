@@ -24,6 +24,8 @@ int fail(int code, const char *fmt, ...);
 
 // out[c] = sum_r x[r * ld + c], two-stage, fixed order (npm_rowops.hip)
 int colsum_launch(const float *x, float *out, long rows, long cols, long ld);
+void set_ln_bwd_blocks(int blocks_per_cu);
+void set_ew_grid_cap(int blocks);
 
 // Pool-backed scratch for split-K slabs and reduction partials; released on scope exit.
 // Safe because every launch goes to the single compute stream (stream-ordered reuse).
