@@ -230,3 +230,17 @@ def test_data_parallel_equivalence_gloo():
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
     assert 'encoder_post' in outs[0]
+
+
+def test_unique_id_exchange_under_launcher():
+    """The RCCL id rendezvous with two ranks under the launcher the driver uses for N > 1
+    (python -m torch.distributed.run, agent store on 127.0.0.1)."""
+    port = _free_port()
+    env = dict(os.environ, OMP_NUM_THREADS='1')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(key, None)
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', 'uid_worker.py')]
+    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    assert out.returncode == 0, out.stdout
+    assert 'rank 0/2: id ok' in out.stdout and 'rank 1/2: id ok' in out.stdout, out.stdout
