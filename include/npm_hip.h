@@ -114,6 +114,7 @@ enum {
     NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never, 1 always, 2 (default) NN/NT */
     NPM_TUNE_LN_BWD_BLOCKS = 6,      /* blocks per CU of the LayerNorm backward grid (default 4) */
     NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
+    NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, -1 unbalanced ceil(3 CUs / tiles) */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);
@@ -129,6 +130,9 @@ int npm_add3(const float *a, const float *b, const float *c, float *out, size_t 
 int npm_axpy(float *y, const float *x, float alpha, size_t n);              /* y += alpha*x; optimizer.py:32 */
 int npm_scale(const float *x, float *y, float alpha, size_t n);
 int npm_colsum(const float *x, float *out, int64_t rows, int64_t cols, int64_t ld); /* mlp.py:34 */
+/* dx = (x_pre >= 0 ? dy : 0) on a contiguous [rows, cols] matrix and colsum[c] = sum_r dx[r, c] in the same
+ * pass: the ReLU backward and the bias gradient of conv.py:54-55 / mlp.py:34,74 (one read of x_pre and dy). */
+int npm_relu_bwd_colsum(const float *x_pre, const float *dy, float *dx, float *colsum, int64_t rows, int64_t cols);
 
 /* ---- row kernels (one wavefront per row) ---------------------------------- */
 /* out[(b*H + h)*S + s] = sum_d a[b,s,h,d] * b[b,s,h,d]: the row term of the fused softmax backward */

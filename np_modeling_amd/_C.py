@@ -84,6 +84,7 @@ SIGNATURES = {
     'npm_axpy': [_P, _P, _F, _SZ],
     'npm_scale': [_P, _P, _F, _SZ],
     'npm_colsum': [_P, _P, _I64, _I64, _I64],
+    'npm_relu_bwd_colsum': [_P, _P, _P, _P, _I64, _I64],
     'npm_attn_rowdot': [_P, _P, _P, _I64, _I64, _I64, _I64],
     'npm_softmax_fwd': [_P, _P, _I64, _I64, _F],
     'npm_softmax_bwd': [_P, _P, _P, _I64, _I64, _F],

@@ -362,12 +362,14 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
     f32x16 acc[2][2];
     zero_acc(acc);
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    // k*k*C0 is rarely a multiple of 128: waves whose 64 rows lie past M only feed the DMA pipeline
+    const bool wave_has_rows = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
     if (nkt > 0) issue(0, 0);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
-        mma_tile16<false, false>(sA, sA + G_TILE, arow, brow, half, acc);
+        if (wave_has_rows) mma_tile16<false, false>(sA, sA + G_TILE, arow, brow, half, acc);
     }
     Epilogue e = p.e;
     const bool raw = p.splits > 1;
@@ -392,6 +394,7 @@ __global__ void flip_transpose_filter_kernel(const float *__restrict__ filt, flo
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
+int g_wgrad_blocks_per_cu = 0;   // NPM_TUNE_CONV_WGRAD_BLOCKS: 0 pick_splits chooses 3 or 4 blocks per CU, 3 / 4 pins it, -1 the old ceil(3 CUs / tiles)
 
 int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
                   const Epilogue &e) {
@@ -429,6 +432,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
 }  // namespace
 
 extern "C" int npm_conv_set_dma(int on) { g_conv_dma = on; return NPM_OK; }
+extern "C" int npm_conv_set_wgrad_blocks(int per_cu) { g_wgrad_blocks_per_cu = per_cu; return NPM_OK; }
 
 extern "C" {
 
@@ -486,8 +490,12 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     const long tiles = (long)a.tiles_m * a.tiles_n;
     const int nkt = (a.K + BK - 1) / BK;
     int splits = 1;
-    if (tiles < 2L * npm::ctx().num_cus && nkt >= 16)
-        splits = (int)std::min<long>((3L * npm::ctx().num_cus + tiles - 1) / tiles, nkt / 8);
+    // 5 tiles x 154 splits = 770 blocks left a quarter of the CUs with 4 blocks and the rest with 3 (19.9 ms at C3);
+    // pick_splits keeps every CU equally full.
+    if (tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
+        if (g_wgrad_blocks_per_cu < 0) splits = (int)std::min<long>((3L * npm::ctx().num_cus + tiles - 1) / tiles, nkt / 8);
+        else splits = pick_splits(tiles, nkt, npm::ctx().num_cus, g_wgrad_blocks_per_cu);
+    }
     splits = std::max(1, splits);
     const int kt_per = (nkt + splits - 1) / splits;
     splits = (nkt + kt_per - 1) / kt_per;

@@ -322,6 +322,7 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 }  // namespace npm_tile
 
 extern "C" int npm_conv_set_dma(int on);
+extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
 
 extern "C" int npm_debug_gemm_trace(long long *buf) { g_trace = buf; return NPM_OK; }
 
@@ -333,6 +334,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_WIDE_TILE: g_wide_tile = value; return NPM_OK;
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
+        case NPM_TUNE_CONV_WGRAD_BLOCKS: return npm_conv_set_wgrad_blocks(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
@@ -406,8 +408,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
-        const long want = (3L * npm::ctx().num_cus + tiles - 1) / tiles;
-        splits = (int)std::min<long>(want, nkt / 8);
+        splits = pick_splits(tiles, nkt, npm::ctx().num_cus);
     }
     if (!linear_epi) splits = 1;
     if (splits > nkt) splits = nkt > 0 ? nkt : 1;

@@ -390,6 +390,25 @@ __device__ __forceinline__ void mma_tile16(const float *__restrict__ sA, const f
 }
 
 // Sum split-K slabs in split order and apply the linear part of the epilogue.
+// Split-K factor for a grid of `tiles` output tiles over `nkt` K tiles.  All blocks of such a launch are
+// resident at once (3-4 fit a CU) and run equally long, so the launch lasts as long as the fullest CU:
+// cost(s) = ceil(tiles * s / CUs) / s.  Candidates leave the fullest CU with 3 or 4 blocks (fewer cannot
+// keep the MFMA pipe busy); ties go to fewer splits.  `force_per_cu` > 0 pins the blocks-per-CU target.
+inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0) {
+    const long max_s = nkt / 8;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int per_cu = 3; per_cu <= 4; ++per_cu) {
+        if (force_per_cu > 0 && per_cu != force_per_cu && !(force_per_cu > 4 && per_cu == 4)) continue;
+        long s = per_cu * cus / tiles;
+        if (s > max_s) s = max_s;
+        if (s < 1) s = 1;
+        const double cost = (double)((tiles * s + cus - 1) / cus) / (double)s;
+        if (cost < best_cost * (1.0 - 1e-6)) { best_cost = cost; best = (int)s; }
+    }
+    return best;
+}
+
 struct ReduceArgs {
     const float *ws;
     long slab;          // elements per split = batch * M * N

@@ -169,26 +169,41 @@ int ew3(const float *a, const float *b, const float *c, float *out, size_t n, F 
 // 16 threads x float4 cover a 256-B row segment, 16 row lanes per block; partial sums
 // cross the row lanes through LDS.  Stage 2 sums the chunk partials (fixed order).
 // ---------------------------------------------------------------------------------
+template <bool RELU_BWD>
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, long cols, long ld,
-              long rows_per_chunk, long out_ld) {
+              long rows_per_chunk, long out_ld, const float *__restrict__ dy, float *__restrict__ g) {
+    // RELU_BWD: x is the pre-activation; g = (x >= 0 ? dy : 0) is stored and summed (activations.py:19 + conv.py:55)
     __shared__ float red[16][65];
     const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
     const long c0 = (long)blockIdx.x * 64 + cq * 4;
     const long r_beg = (long)blockIdx.y * rows_per_chunk;
     const long r_end = min(rows, r_beg + rows_per_chunk);
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    const bool full = (c0 + 3 < cols) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    bool full = (c0 + 3 < cols) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
+    if (RELU_BWD) full = full && ((((uintptr_t)dy) & 15) == 0) && ((((uintptr_t)g) & 15) == 0);
     for (long r = r_beg + rl; r < r_end; r += 16) {
-        const float *p = x + r * ld + c0;
+        const long at = r * ld + c0;
+        const float *p = x + at;
         if (full) {
-            const float4 v = *reinterpret_cast<const float4 *>(p);
+            float4 v = *reinterpret_cast<const float4 *>(p);
+            if (RELU_BWD) {
+                const float4 d = *reinterpret_cast<const float4 *>(dy + at);
+                v.x = v.x >= 0.f ? d.x : 0.f; v.y = v.y >= 0.f ? d.y : 0.f;
+                v.z = v.z >= 0.f ? d.z : 0.f; v.w = v.w >= 0.f ? d.w : 0.f;
+                *reinterpret_cast<float4 *>(g + at) = v;
+            }
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         } else {
-            if (c0 + 0 < cols) acc.x += p[0];
-            if (c0 + 1 < cols) acc.y += p[1];
-            if (c0 + 2 < cols) acc.z += p[2];
-            if (c0 + 3 < cols) acc.w += p[3];
+            float *a4 = &acc.x;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (c0 + j < cols) {
+                    float v = p[j];
+                    if (RELU_BWD) { v = v >= 0.f ? dy[at + j] : 0.f; g[at + j] = v; }
+                    a4[j] += v;
+                }
+            }
         }
     }
     red[rl][cq * 4 + 0] = acc.x; red[rl][cq * 4 + 1] = acc.y;
@@ -203,25 +218,34 @@ colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, l
     }
 }
 
-int colsum_impl(const float *x, float *out, long rows, long cols, long ld) {
+template <bool RELU_BWD>
+int colsum_run(const float *x, float *out, long rows, long cols, long ld, const float *dy, float *g) {
     hipStream_t s = npm::ctx().stream;
+    if (rows <= 0) return ew1(out, out, (size_t)cols, FillF{0.f});          // an empty batch sums to zero
     const int strips = (int)((cols + 63) / 64);
     long chunks = std::max<long>(1, std::min<long>((rows + 255) / 256, std::max<long>(1, 2048 / strips)));
     const long rpc = (rows + chunks - 1) / chunks;
     chunks = (rows + rpc - 1) / rpc;
     if (chunks <= 1) {
-        hipLaunchKernelGGL(colsum_kernel, dim3(strips, 1), dim3(256), 0, s, x, out, rows, cols, ld, std::max<long>(rows, 1), cols);
+        hipLaunchKernelGGL(colsum_kernel<RELU_BWD>, dim3(strips, 1), dim3(256), 0, s, x, out, rows, cols, ld,
+                           std::max<long>(rows, 1), cols, dy, g);
         NPM_CHECK_LAUNCH();
         return NPM_OK;
     }
     npm::Scratch part;
     int rc = part.alloc(sizeof(float) * (size_t)chunks * cols);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel, dim3(strips, (int)chunks), dim3(256), 0, s, x, (float *)part.ptr, rows, cols, ld, rpc, cols);
+    hipLaunchKernelGGL(colsum_kernel<RELU_BWD>, dim3(strips, (int)chunks), dim3(256), 0, s, x, (float *)part.ptr, rows, cols, ld,
+                       rpc, cols, dy, g);
     NPM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_kernel, dim3(strips, 1), dim3(256), 0, s, (const float *)part.ptr, out, chunks, cols, cols, chunks, cols);
+    hipLaunchKernelGGL(colsum_kernel<false>, dim3(strips, 1), dim3(256), 0, s, (const float *)part.ptr, out, chunks, cols, cols,
+                       chunks, cols, (const float *)nullptr, (float *)nullptr);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
+}
+
+int colsum_impl(const float *x, float *out, long rows, long cols, long ld) {
+    return colsum_run<false>(x, out, rows, cols, ld, nullptr, nullptr);
 }
 
 // ---------------------------------------------------------------------------------
@@ -572,6 +596,14 @@ int npm_colsum(const float *x, float *out, int64_t rows, int64_t cols, int64_t l
     if (cols == 0) return NPM_OK;
     NPM_ARG(out != nullptr && (x != nullptr || rows == 0));
     return colsum_impl(x, out, rows, cols, ld);
+}
+
+int npm_relu_bwd_colsum(const float *x_pre, const float *dy, float *dx, float *colsum, int64_t rows, int64_t cols) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && cols >= 0);
+    if (cols == 0) return NPM_OK;
+    NPM_ARG(colsum != nullptr && ((x_pre && dy && dx) || rows == 0));
+    return colsum_run<true>(x_pre, colsum, rows, cols, cols, dy, dx);
 }
 
 #define NPM_ROW_DISPATCH(KERNEL, n, ...)                                                       \

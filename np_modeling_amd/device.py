@@ -528,6 +528,18 @@ def relu_bwd(x_pre: DeviceArray, dy: DeviceArray, out: Optional[DeviceArray] = N
     return out
 
 
+def relu_bwd_colsum(x_pre: DeviceArray, dy: DeviceArray, cols: int, colsum_out: DeviceArray) -> DeviceArray:
+    """ReLU backward of a [rows, cols] matrix and the column sums of the result (the bias gradient of the
+    layer in front of the ReLU) in one pass: conv.py:54-55, mlp.py:74 + mlp.py:34."""
+    out = empty(dy.shape)
+    rows = dy.size // cols
+    assert rows * cols == dy.size and x_pre.size == dy.size and colsum_out.size == cols
+    with _timed('relu_bwd_colsum', nbytes=12.0 * dy.size):
+        _C.check(_C.lib().npm_relu_bwd_colsum(x_pre.ptr, dy.ptr, out.ptr, colsum_out.ptr, rows, cols),
+                 'npm_relu_bwd_colsum')
+    return out
+
+
 def softmax_fwd(x: DeviceArray, scale: float = 1.0, out: Optional[DeviceArray] = None) -> DeviceArray:
     n = x.shape[-1] if x.ndim else 1
     rows = x.size // n if n else 0

@@ -54,7 +54,9 @@ class Conv2D(layer.StatefulLayer):
         pre = D.empty([n, h, wd, c1]) if fused else None
         desc = _C.npm_conv2d(n=n, h=h, w=wd, c_in=c0, c_out=c1, ksize=k, x=x.ptr, filt=w.ptr, bias=b.ptr,
                              y=y.ptr, pre=pre.ptr if fused else None, relu=int(fused))
-        _C.check(_C.lib().npm_conv2d_fwd(C.byref(desc)), 'npm_conv2d_fwd')
+        flops = 2.0 * n * h * wd * c1 * k * k * c0
+        with D._timed('conv2d_fwd', flops):
+            _C.check(_C.lib().npm_conv2d_fwd(C.byref(desc)), 'npm_conv2d_fwd')
         if fused:
             self._activation._x = pre
             return y
@@ -68,13 +70,19 @@ class Conv2D(layer.StatefulLayer):
         n, h, wd, c0 = x.shape
         k, c1 = self._kernel_size, self._output_channels
         with parallel.grad_scope(w.size + c1 + 8) as scope:
-            g = D.as_device(self._activation.backward(dy))
             db = scope.take([c1])
-            D.colsum(g, n * h * wd, c1, out=db)
+            if self._fused_relu():           # relu' and db (conv.py:54-55) in one pass over dy
+                g = D.relu_bwd_colsum(self._activation._x, dy, c1, db)
+            else:
+                g = D.as_device(self._activation.backward(dy))
+                D.colsum(g, n * h * wd, c1, out=db)
             dw = scope.take(w.shape)
-            _C.check(_C.lib().npm_conv2d_bwd_w(g.ptr, x.ptr, dw.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_w')
+            flops = 2.0 * n * h * wd * c1 * k * k * c0
+            with D._timed('conv2d_bwd_w', flops):
+                _C.check(_C.lib().npm_conv2d_bwd_w(g.ptr, x.ptr, dw.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_w')
             dx = D.empty(x.shape)
-            _C.check(_C.lib().npm_conv2d_bwd_x(g.ptr, w.ptr, dx.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_x')
+            with D._timed('conv2d_bwd_x', flops):
+                _C.check(_C.lib().npm_conv2d_bwd_x(g.ptr, w.ptr, dx.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_x')
             assert dx.shape == x.shape
             scope.defer(optimizer_, self, '_w', dw)
             scope.defer(optimizer_, self, '_b', db)

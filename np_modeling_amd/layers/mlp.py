@@ -124,8 +124,12 @@ class Dense(layer.StatefulLayer):
     def backward(self, dy, optimizer_):
         lin = self._linear
         with parallel.grad_scope(lin._w.size + lin._b.size + 8) as scope:
-            dy = self._activation.backward(D.as_device(dy))
-            return lin._backward_impl(dy, optimizer_, scope)
+            dy = D.as_device(dy)
+            if self._fused_relu():           # relu' (mlp.py:74) and db (mlp.py:34) in one pass over dy
+                db = scope.take([lin._output_units])
+                g = D.relu_bwd_colsum(self._activation._x, dy, lin._output_units, db)
+                return lin._backward_impl(g, optimizer_, scope, db=db)
+            return lin._backward_impl(self._activation.backward(dy), optimizer_, scope)
 
     @property
     def linear(self) -> Linear:

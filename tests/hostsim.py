@@ -178,6 +178,13 @@ class HostSim:
         _vec(out, cols)[:] = _mat(x, rows, cols, ld).astype(np.float64).sum(axis=0)
         return 0
 
+    def npm_relu_bwd_colsum(self, x, dy, dx, colsum, rows, cols):
+        n = rows * cols
+        g = np.where(_vec(x, n) >= 0, _vec(dy, n), 0)
+        _vec(dx, n)[:] = g
+        _vec(colsum, cols)[:] = g.reshape(rows, cols).astype(np.float64).sum(axis=0)
+        return 0
+
     # ---- row kernels ---------------------------------------------------------------------------
     def npm_attn_rowdot(self, a, b, out, batch, seq, heads, dim):
         n = int(batch * seq * heads * dim)

@@ -52,12 +52,51 @@ def test_elementwise_unaligned_views(env):
     np.testing.assert_array_equal(out.numpy(), 2 * np.arange(1, 998, dtype=np.float32))
 
 
-@pytest.mark.parametrize('rows,cols', [(1, 1), (7, 5), (1000, 64), (4099, 130), (20000, 1024), (3, 4096)])
+@pytest.mark.parametrize('rows,cols', [(0, 6), (1, 1), (7, 5), (1000, 64), (4099, 130), (20000, 1024), (3, 4096)])
 def test_colsum(env, rows, cols):
     _C, D = env
     x = np.random.default_rng(rows + cols).standard_normal((rows, cols)).astype(np.float32)
     out = D.colsum(D.from_host(x), rows, cols)
     assert_close(out, x.astype(np.float64).sum(axis=0), tol=2e-6)
+
+
+@pytest.mark.parametrize('rows,cols', [(0, 8), (1, 1), (7, 5), (1000, 64), (4099, 130), (50000, 128), (3, 4096)])
+def test_relu_bwd_colsum(env, rows, cols):
+    """ReLU backward + bias gradient in one pass (activations.py:19 then conv.py:55 / mlp.py:34)."""
+    _C, D = env
+    rng = np.random.default_rng(rows * 7 + cols)
+    pre = rng.standard_normal((rows, cols)).astype(np.float32)
+    dy = rng.standard_normal((rows, cols)).astype(np.float32)
+    if rows:
+        pre[0, : min(cols, 3)] = 0.0                 # x == 0 passes the gradient (>=)
+        if cols > 1:
+            pre[-1, 1] = -0.0
+    out = D.from_host(np.full(cols, 9.0, dtype=np.float32))
+    g = D.relu_bwd_colsum(D.from_host(pre), D.from_host(dy), cols, out)
+    want = O.relu_bwd(pre, dy).astype(np.float32)
+    np.testing.assert_array_equal(g.numpy(), want)
+    assert_close(out, want.astype(np.float64).sum(axis=0), tol=2e-6)
+
+
+def test_relu_bwd_colsum_unaligned(env):
+    _C, D = env
+    rows, cols = 37, 12
+    rng = np.random.default_rng(5)
+    pre = rng.standard_normal((rows, cols)).astype(np.float32)
+    dy = rng.standard_normal((rows, cols)).astype(np.float32)
+    base_pre, base_dy = D.empty([rows * cols + 1]), D.empty([rows * cols + 1])
+    vp, vd = base_pre.flat_view(1, [rows, cols]), base_dy.flat_view(1, [rows, cols])     # 4-byte offset
+    vp.set(pre)
+    vd.set(dy)
+    guard = D.from_host(np.full(rows * cols + 2, 7.0, dtype=np.float32))
+    g = guard.flat_view(1, [rows, cols])
+    out = D.empty([cols])
+    _C.check(_C.lib().npm_relu_bwd_colsum(vp.ptr, vd.ptr, g.ptr, out.ptr, rows, cols))
+    want = np.where(pre >= 0, dy, 0).astype(np.float32)
+    host = guard.numpy()
+    np.testing.assert_array_equal(host[1:-1].reshape(rows, cols), want)
+    assert host[0] == 7.0 and host[-1] == 7.0
+    assert_close(out, want.astype(np.float64).sum(axis=0), tol=2e-6)
 
 
 @pytest.mark.parametrize('rows,n', [(1, 1), (5, 3), (128, 128), (33, 40), (64, 512), (10, 1000), (7, 4096),

@@ -19,6 +19,9 @@ import numpy as np  # noqa: E402
 PEAK = 157.3
 
 
+KERNELS = False
+
+
 def timed(fn, steps, D):
     fn()
     D.synchronize()
@@ -26,7 +29,16 @@ def timed(fn, steps, D):
     for _ in range(steps):
         fn()
     D.synchronize()
-    return (time.perf_counter() - t0) / steps
+    sec = (time.perf_counter() - t0) / steps
+    if KERNELS:                                   # one more step under the event timer: per-kernel table
+        with D.KernelTimer() as timer:
+            fn()
+        rows = sorted(timer.summary().items(), key=lambda kv: -kv[1]['ms'])
+        for name, r in rows:
+            rate = (f"{r['flops'] / r['ms'] / 1e9:7.1f} TFLOP/s" if r['flops'] else
+                    f"{r['bytes'] / r['ms'] / 1e6:7.0f} GB/s   ")
+            print(f"    {name:<22s} x{r['launches']:<3d} {r['ms']:8.3f} ms  {rate}", flush=True)
+    return sec
 
 
 def main():
@@ -34,7 +46,10 @@ def main():
     ap.add_argument('--steps', type=int, default=3)
     ap.add_argument('--only', default='')
     ap.add_argument('--conv-batch', type=int, default=256)
+    ap.add_argument('--kernels', action='store_true', help='per-kernel HIP-event table after each line')
     args = ap.parse_args()
+    global KERNELS
+    KERNELS = args.kernels
     import np_modeling_amd as npm
     from np_modeling_amd import device as D
     rng = np.random.default_rng(0)
