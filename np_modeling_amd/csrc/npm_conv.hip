@@ -221,6 +221,7 @@ conv_fwd_glds_kernel(const ConvArgs p) {
     constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
     constexpr int A_PIECES = TM / 64, B_PIECES = TN / 64;     // 1 KiB DMA pieces per wave and tile
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    prio_high(p.e.prio & 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = TALL ? wave : wave >> 1, wn = TALL ? 0 : wave & 1, l32 = lane & 31, half = lane >> 5;
@@ -285,6 +286,7 @@ conv_fwd_glds_kernel(const ConvArgs p) {
     zero_acc(acc);
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
     if (nkt > 0) NPM_CONV_ISSUE(0, 0);
+    prio_low(p.e.prio & 1);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
         if (kt + 1 < nkt) NPM_CONV_ISSUE(kt + 1, (kt + 1) & 1);
@@ -292,6 +294,7 @@ conv_fwd_glds_kernel(const ConvArgs p) {
         mma_tile16<true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc);
     }
 #undef NPM_CONV_ISSUE
+    prio_high(p.e.prio & 2);
     if (p.e.buf_ok) write_tile_buf(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
     else write_tile(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
@@ -300,6 +303,7 @@ conv_fwd_glds_kernel(const ConvArgs p) {
 __global__ void __launch_bounds__(NTHREADS, 4)
 conv_wgrad_glds_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
+    prio_high(p.e.prio & 1);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
@@ -365,12 +369,14 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
     // k*k*C0 is rarely a multiple of 128: waves whose 64 rows lie past M only feed the DMA pipeline
     const bool wave_has_rows = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
     if (nkt > 0) issue(0, 0);
+    prio_low(p.e.prio & 1);
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
         if (wave_has_rows) mma_tile16<false, false>(sA, sA + G_TILE, arow, brow, half, acc);
     }
+    prio_high(p.e.prio & 2);
     Epilogue e = p.e;
     const bool raw = p.splits > 1;
     if (raw) e.ws += (long)split * p.slab;
@@ -394,6 +400,7 @@ __global__ void flip_transpose_filter_kernel(const float *__restrict__ filt, flo
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
+int g_conv_wave_prio = 0;   // NPM_TUNE_GEMM_WAVE_PRIO
 int g_wgrad_blocks_per_cu = 0;   // NPM_TUNE_CONV_WGRAD_BLOCKS: 0 pick_splits chooses 3 or 4 blocks per CU, 3 / 4 pins it, -1 the old ceil(3 CUs / tiles)
 
 int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
@@ -412,6 +419,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     hipStream_t s = npm::ctx().stream;
     const long halo = (long)a.pad * w + a.pad;
     a.e.buf_ok = g_conv_dma && (256L * n_out + n_out) * 4 < (1L << 31);
+    a.e.prio = g_conv_wave_prio;
     const bool dma = g_conv_dma && vec && c % GK == 0 && (256 + 2 * halo) * c * 4 < (1L << 30) &&
                      (long)a.K * n_out * 4 < (1L << 31);
     const bool tall = dma && n_out <= 64 && n_out % 16 == 0 && g_conv_dma != 2;
@@ -433,6 +441,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
 
 extern "C" int npm_conv_set_dma(int on) { g_conv_dma = on; return NPM_OK; }
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu) { g_wgrad_blocks_per_cu = per_cu; return NPM_OK; }
+extern "C" int npm_conv_set_wave_prio(int bits) { g_conv_wave_prio = bits; return NPM_OK; }
 
 extern "C" {
 
@@ -514,6 +523,7 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     const int grid = (int)(tiles * splits);
     const long halo = (long)a.pad * w + a.pad;
     a.e.buf_ok = g_conv_dma && (256L * a.N + a.N) * 4 < (1L << 31);
+    a.e.prio = g_conv_wave_prio;
     const bool dma = g_conv_dma && vec && pixels % GK == 0 && a.k_per_split % GK == 0 &&
                      ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) &&
                      (long)a.k_per_split * c_out * 4 < (1L << 30);

@@ -40,7 +40,7 @@ struct GemmArgs {
     int group_m;
     long long *trace; // diagnostics: 8 words per block (hw id, xcc id, 4 s_memtime stamps) or null
     int wide;        // 128 x 256 block tile (2 x 4 waves) instead of 128 x 128
-    int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers
+    int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers, 8 skip the epilogue
     long slab;       // split-K: batch * M * N
     Epilogue e;
 };
@@ -48,6 +48,7 @@ struct GemmArgs {
 int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline where eligible
 int g_group_m = 8;
 int g_ablate = 0;
+int g_wave_prio = 0;               // NPM_TUNE_GEMM_WAVE_PRIO
 int g_wide_tile = 0;               // NPM_TUNE_GEMM_WIDE_TILE: 128 x 256 tile where n % 256 == 0: 0 never, 1 always, 2 NN/NT, 3 NT only
 long long *g_trace = nullptr;    // diagnostics: per-block timeline stamps (npm_debug_gemm_trace)
 int g_buf_epilogue = 1;
@@ -161,6 +162,7 @@ sgemm_glds_kernel(const GemmArgs p) {
     static_assert(A_PW * WM * WN * 16 == TM && B_PW * WM * WN * 16 == TN, "pieces must tile the operands");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
 
+    prio_high(p.e.prio & 1);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -221,6 +223,7 @@ sgemm_glds_kernel(const GemmArgs p) {
     long long t_start = 0, t_first = 0, t_loop = 0, r_start = 0;
     if (p.trace) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
     if (nkt > 0) issue(0, 0);
+    prio_low(p.e.prio & 1);
     for (int kt = 0; kt < nkt; ++kt) {
         // tile kt has landed (every wave's pieces) and everybody is done reading the other stage
         if (!(p.ablate & 4)) __syncthreads();
@@ -232,10 +235,11 @@ sgemm_glds_kernel(const GemmArgs p) {
     }
 
     if (p.trace) t_loop = __builtin_amdgcn_s_memtime();
+    prio_high(p.e.prio & 2);
     struct TraceOnExit {
         long long *buf, t0, t1, t2, r0;
         int tid;
-        __device__ ~TraceOnExit() {
+        __device__ __forceinline__ ~TraceOnExit() {
             if (buf && tid == 0) {
                 const long long t_issued = __builtin_amdgcn_s_memtime();
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stores of this wave have left
@@ -248,6 +252,10 @@ sgemm_glds_kernel(const GemmArgs p) {
             }
         }
     } trace_guard{p.trace, t_start, t_first, t_loop, r_start, tid};
+    if (p.ablate & 8) {          // timing only: one store per lane keeps the accumulators alive
+        if (acc[0][0][0] + acc[0][1][5] + acc[1][0][9] + acc[1][1][15] == 12345.f) p.e.C[tid] = 0.f;
+        return;
+    }
     Epilogue e = p.e;
     if (p.splits > 1) {
         e.ws += (long)split * p.slab + (long)z * p.M * p.N;
@@ -323,6 +331,7 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 
 extern "C" int npm_conv_set_dma(int on);
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
+extern "C" int npm_conv_set_wave_prio(int bits);
 
 extern "C" int npm_debug_gemm_trace(long long *buf) { g_trace = buf; return NPM_OK; }
 
@@ -335,6 +344,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         case NPM_TUNE_CONV_WGRAD_BLOCKS: return npm_conv_set_wgrad_blocks(value);
+        case NPM_TUNE_GEMM_WAVE_PRIO: g_wave_prio = value; return npm_conv_set_wave_prio(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
@@ -396,6 +406,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     }
     a.group_m = g_group_m;
     a.ablate = g_ablate;
+    a.e.prio = g_wave_prio;
     a.trace = g_trace;
 
     const long batch = (long)g->batch0 * g->batch1;

@@ -32,7 +32,13 @@ struct Epilogue {
     int buf_ok;              // every extent (C, residual, aux, slab) < 2^31 bytes: buffer-instruction epilogue
     float *cs;               // optional column-sum partials: one row of N per (tile row, wave row)
     long cs_wm;              // elements between the partial rows of wave rows wm = 0 and 1
+    int prio;                // NPM_TUNE_GEMM_WAVE_PRIO: bit 0 raise the wave's issue priority in the prologue, bit 1 in the epilogue
 };
+
+// Wave issue priority (s_setprio).  Three of the four blocks of a CU are always inside their MFMA loops; the
+// scalar/vector ALU work of a block's prologue and epilogue competes with their back-to-back MFMAs for issue.
+__device__ __forceinline__ void prio_high(int on) { if (on) __builtin_amdgcn_s_setprio(3); }
+__device__ __forceinline__ void prio_low(int on) { if (on) __builtin_amdgcn_s_setprio(0); }
 
 // Bijective XCD-contiguous remap: blocks b and b+8 share an XCD (and its L2), so give each
 // XCD one contiguous run of logical tiles.
@@ -167,6 +173,88 @@ __device__ __forceinline__ void write_tile(const f32x16 (&acc)[2][2], const Epil
         }
 }
 
+// Per-wave state handed from write_tile_buf to the read-modify-write epilogue below.
+struct RmwArgs {
+    __amdgpu_buffer_rsrc_t rc;
+    int vc[2];
+    float bias[2];
+    int ldc, row0, rows_here, flags, m0, n0, N, wn, l32, half;
+    float alpha;
+    float *cptr;
+};
+
+// F >= 0: the NPM_EPI_* flags (bit 6 = alpha is 1) are compile-time constants; F < 0: read them at run time.
+// Per 32x32 MFMA tile: issue its 16 (or 32) loads together, wait once, then compute and store.
+template <int F, bool CS>
+__device__ __forceinline__ void rmw_epilogue(const f32x16 (&acc)[2][2], const Epilogue &e, const RmwArgs &a, float (&csum)[2]) {
+    constexpr int OOB = 0x7FFFFFFF;
+    const int flags = F >= 0 ? F : a.flags;
+    const bool has_bias = F >= 0 ? (F & NPM_EPI_BIAS) != 0 : true;        // run time: bias[] is 0 when absent
+    const bool has_res = (flags & NPM_EPI_RESIDUAL) != 0;
+    const bool relu_save = (flags & NPM_EPI_RELU_SAVE) != 0;
+    const bool relu_mask = (flags & NPM_EPI_RELU_MASK) != 0;
+    const bool relu = (flags & NPM_EPI_RELU) != 0;
+    const bool sm_bwd = (flags & NPM_EPI_SOFTMAX_BWD) != 0;
+    const bool alpha_one = F >= 0 && (F & 64) != 0;
+    const float alpha = a.alpha;
+    const int ldc = a.ldc, row0 = a.row0, half = a.half, rows_here = a.rows_here;
+    const int ldr = has_res ? (int)e.ldr : 0;
+    const bool use_aux = relu_save || relu_mask || sm_bwd;
+    const int ldx = use_aux ? (int)e.ldaux : 0;
+    const auto rv = __builtin_amdgcn_make_buffer_rsrc((void *)(sm_bwd ? e.rowvec + a.m0 : a.cptr), 0, sm_bwd ? rows_here * 4 : 0, 0x00020000);
+    const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R + (long)a.m0 * ldr : a.cptr), 0,
+                                                      has_res ? (int)(((long)(rows_here - 1) * ldr + a.N) * 4) : 0, 0x00020000);
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(use_aux ? e.aux + (long)a.m0 * ldx : a.cptr), 0,
+                                                      use_aux ? (int)(((long)(rows_here - 1) * ldx + a.N) * 4) : 0, 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = a.n0 + a.wn * 64 + j * 32 + a.l32;
+        const int vr = col < a.N ? (4 * half * ldr + col) * 4 : OOB;
+        const int vx = col < a.N ? (4 * half * ldx + col) * 4 : OOB;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            float res[16], msk[16];
+            if (has_res) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vr, row * ldr * 4, 0));
+                }
+            }
+            if (relu_mask || sm_bwd) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    msk[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, row * ldx * 4, 0));
+                }
+            }
+            if (sm_bwd) {   // res[] doubles as the per-row term (a residual is not combined with this mode)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, 16 * half, row * 4, 0));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                float v = alpha_one ? acc[i][j][r] : alpha * acc[i][j][r];
+                if (has_bias) v += a.bias[j];
+                if (sm_bwd) v = alpha * msk[r] * (acc[i][j][r] - res[r]);
+                else if (has_res) v += res[r];
+                if (relu_save) {
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rx, vx, row * ldx * 4, 0);
+                    v = fmaxf(v, 0.f);
+                }
+                if (relu_mask) v = msk[r] >= 0.f ? v : 0.f;
+                if (relu) v = fmaxf(v, 0.f);
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), a.rc, a.vc[j], row * ldc * 4, 0);
+                if (CS && row + 4 * half < rows_here) csum[j] += v;
+            }
+        }
+    }
+}
+
 // Branch-free epilogue through buffer instructions.  Each store is ONE instruction:
 // the per-lane column offset sits in the VGPR offset (computed once), the row offset is a
 // scalar (soffset) and rows >= M / columns >= N are dropped by the descriptor's range check
@@ -202,78 +290,60 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
     const int row0 = wm * 64;                          // wave-uniform, relative to the block's first row
 
     if (!has_res && !relu_save && !relu_mask && !sm_bwd) {
-        // Store-only epilogues (plain, bias, relu): 64 stores back to back, nothing to wait for.
+        // Store-only epilogues (plain, bias, relu): 64 stores back to back, nothing to wait for.  Vector-ALU
+        // instructions of an epilogue issue slowly beside three blocks of back-to-back MFMAs (measured: 64 raw
+        // stores 5 us, with 3 VALU each 25 us), so the common cases run specialised code with 0 or 1 per store.
+        const bool simple = !relu && !(WITH_COLSUM && want_cs);
+#define NPM_STORE_ONLY(EXPR)                                                                           \
+        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                                  \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                               \
+            const int sc = (row0 + i * 32 + (r & 3) + 8 * (r >> 2)) * ldc * 4;                         \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                            \
+                const float a = acc[i][j][r];                                                          \
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(EXPR), rc, vc[j], sc, 0);        \
+            }                                                                                          \
+        }
+        if (simple && !has_bias && alpha == 1.f) {
+            NPM_STORE_ONLY(a)
+        } else if (simple && !has_bias) {
+            NPM_STORE_ONLY(alpha * a)
+        } else if (simple && alpha == 1.f) {
+            NPM_STORE_ONLY(a + bias[j])
+        } else {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                const int sc = row * ldc * 4;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    float v = alpha * acc[i][j][r] + bias[j];
-                    if (relu) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
-                    if (WITH_COLSUM && want_cs && row + 4 * half < rows_here) csum[j] += v;
-                }
-            }
-    } else {
-        // Epilogues that READ (residual / ReLU mask) or write twice (ReLU with saved pre-activation):
-        // per 32x32 MFMA tile, issue its 16 loads together, wait once, then compute and store.
-        const int ldr = has_res ? (int)e.ldr : 0;
-        const bool use_aux = relu_save || relu_mask || sm_bwd;
-        const int ldx = use_aux ? (int)e.ldaux : 0;
-        const auto rv = __builtin_amdgcn_make_buffer_rsrc((void *)(sm_bwd ? e.rowvec + m0 : cptr), 0, sm_bwd ? rows_here * 4 : 0, 0x00020000);
-        const auto rr = __builtin_amdgcn_make_buffer_rsrc((void *)(has_res ? e.R + (long)m0 * ldr : cptr), 0,
-                                                          has_res ? (int)(((long)(rows_here - 1) * ldr + N) * 4) : 0, 0x00020000);
-        const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(use_aux ? e.aux + (long)m0 * ldx : cptr), 0,
-                                                          use_aux ? (int)(((long)(rows_here - 1) * ldx + N) * 4) : 0, 0x00020000);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l32;
-            const int vr = col < N ? (4 * half * ldr + col) * 4 : OOB;
-            const int vx = col < N ? (4 * half * ldx + col) * 4 : OOB;
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                float res[16], msk[16];
-                if (has_res) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rr, vr, row * ldr * 4, 0));
-                    }
-                }
-                if (relu_mask || sm_bwd) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        msk[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, row * ldx * 4, 0));
-                    }
-                }
-                if (sm_bwd) {   // res[] doubles as the per-row term (a residual is not combined with this mode)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                        res[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rv, 16 * half, row * 4, 0));
-                    }
-                }
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
-                    float v = alpha * acc[i][j][r] + bias[j];
-                    if (sm_bwd) v = alpha * msk[r] * (acc[i][j][r] - res[r]);
-                    else if (has_res) v += res[r];
-                    if (relu_save) {
-                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rx, vx, row * ldx * 4, 0);
-                        v = fmaxf(v, 0.f);
+                    const int sc = row * ldc * 4;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        float v = alpha * acc[i][j][r] + bias[j];
+                        if (relu) v = fmaxf(v, 0.f);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], sc, 0);
+                        if (WITH_COLSUM && want_cs && row + 4 * half < rows_here) csum[j] += v;
                     }
-                    if (relu_mask) v = msk[r] >= 0.f ? v : 0.f;
-                    if (relu) v = fmaxf(v, 0.f);
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), rc, vc[j], row * ldc * 4, 0);
-                    if (WITH_COLSUM && want_cs && row + 4 * half < rows_here) csum[j] += v;
                 }
-            }
         }
+#undef NPM_STORE_ONLY
+    } else {
+        // Epilogues that READ (residual / ReLU mask / softmax-backward operand) or write twice (ReLU with saved
+        // pre-activation).  The flag combinations the layers use run code specialised at compile time (no
+        // per-element flag tests, the minimum of vector-ALU work); anything else takes the generic instance.
+        RmwArgs a;
+        a.rc = rc; a.vc[0] = vc[0]; a.vc[1] = vc[1]; a.bias[0] = bias[0]; a.bias[1] = bias[1];
+        a.ldc = ldc; a.row0 = row0; a.rows_here = rows_here; a.alpha = alpha; a.flags = flags;
+        a.m0 = m0; a.n0 = n0; a.N = N; a.wn = wn; a.l32 = l32; a.half = half; a.cptr = cptr;
+        const bool cs = WITH_COLSUM && want_cs;
+        const int key = flags | (alpha == 1.f ? 64 : 0);
+        if (key == (NPM_EPI_BIAS | NPM_EPI_RESIDUAL | 64)) rmw_epilogue<NPM_EPI_BIAS | NPM_EPI_RESIDUAL | 64, false>(acc, e, a, csum);
+        else if (key == (NPM_EPI_RESIDUAL | 64) && !cs) rmw_epilogue<NPM_EPI_RESIDUAL | 64, false>(acc, e, a, csum);
+        else if (key == (NPM_EPI_BIAS | NPM_EPI_RELU_SAVE | 64)) rmw_epilogue<NPM_EPI_BIAS | NPM_EPI_RELU_SAVE | 64, false>(acc, e, a, csum);
+        else if (key == (NPM_EPI_RELU_MASK | 64)) { if (cs) rmw_epilogue<NPM_EPI_RELU_MASK | 64, WITH_COLSUM>(acc, e, a, csum);
+                                                    else rmw_epilogue<NPM_EPI_RELU_MASK | 64, false>(acc, e, a, csum); }
+        else if (key == (NPM_EPI_RELU_MASK | NPM_EPI_RESIDUAL | 64) && !cs) rmw_epilogue<NPM_EPI_RELU_MASK | NPM_EPI_RESIDUAL | 64, false>(acc, e, a, csum);
+        else if ((key & ~64) == NPM_EPI_SOFTMAX_BWD && !cs) rmw_epilogue<NPM_EPI_SOFTMAX_BWD, false>(acc, e, a, csum);
+        else { if (cs) rmw_epilogue<-1, WITH_COLSUM>(acc, e, a, csum); else rmw_epilogue<-1, false>(acc, e, a, csum); }
     }
     if (WITH_COLSUM && want_cs) {   // this wave's 64 rows summed per column: rows live in the registers and the two lane halves
 #pragma unroll

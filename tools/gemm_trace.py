@@ -7,14 +7,22 @@ sys.path.insert(0, ROOT)
 import numpy as np
 from np_modeling_amd import device as D, _C
 
-M, N, K = 131072, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+# usage: gemm_trace.py [K]            -> 131072 x 1024 x K, NN
+#        gemm_trace.py qk             -> the attention score GEMM: 2048 x (512 x 512 x 128), NT
+if len(sys.argv) > 1 and sys.argv[1] == 'qk':
+    M, N, K, NB, NT = 512, 512, 128, 2048, True
+else:
+    M, N, K, NB, NT = 131072, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 1, False
 rng = np.random.default_rng(0)
-a = D.from_host(rng.standard_normal(M * K, dtype=np.float32))
-b = D.from_host(rng.standard_normal(K * N, dtype=np.float32))
-c = D.empty([M * N])
-grid = (M // 128) * (N // 128)
+a = D.from_host(rng.standard_normal(NB * M * K, dtype=np.float32))
+b = D.from_host(rng.standard_normal(NB * K * N, dtype=np.float32))
+c = D.empty([NB * M * N])
+grid = NB * (M // 128) * (N // 128)
 buf = D._Buffer(grid * 64)
-fn = lambda: D.gemm(M, N, K, D.Mat(a, K), D.Mat(b, N), D.Mat(c, N))
+if NT:
+    fn = lambda: D.gemm(M, N, K, D.Mat(a, K, M * K), D.Mat(b, K, N * K), D.Mat(c, N, M * N), trans_b=True, batch=(NB, 1))
+else:
+    fn = lambda: D.gemm(M, N, K, D.Mat(a, K), D.Mat(b, N), D.Mat(c, N))
 fn(); fn(); D.synchronize()
 _C.check(_C.lib().npm_debug_gemm_trace(buf.ptr))
 fn(); D.synchronize()
@@ -26,7 +34,12 @@ hw, xcc = t[:, 0], t[:, 1] & 0xF
 cu = (hw >> 8) & 0xF; sh = (hw >> 12) & 1; se = (hw >> 13) & 0x7; simd = (hw >> 4) & 3; wave_slot = hw & 0xF
 t0 = t[:, 2].min()
 start, first, loop, end, issued = (t[:, i] - t0 for i in (2, 3, 4, 5, 6))
-print(f'K={K} blocks={grid}; clock ticks (s_memtime)')
+real = t[:, 7]
+us = float(np.median(real / np.maximum(end - start, 1))) * 0.01       # microseconds per s_memtime tick
+print(f'K={K} blocks={grid}; s_memtime ticks, 1 tick = {us * 1000:.3f} ns')
+print('in us: prologue %.2f | main loop %.2f (per k-tile %.3f) | epilogue issue %.2f, drained %.2f | lifetime %.1f | kernel span %.1f' % (
+    np.median(first - start) * us, np.median(loop - first) * us, np.median(loop - first) / (K // 16) * us,
+    np.median(issued - loop) * us, np.median(end - loop) * us, np.median(end - start) * us, float(end.max()) * us))
 print('prologue (start->first tile landed): median %d  p90 %d' % (np.median(first - start), np.percentile(first - start, 90)))
 print('main loop: median %d  (per k-tile %d)' % (np.median(loop - first), np.median(loop - first) / (K // 16)))
 print('epilogue (loop end->stores drained): median %d p90 %d' % (np.median(end - loop), np.percentile(end - loop, 90)))
