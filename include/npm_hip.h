@@ -99,6 +99,13 @@ typedef struct npm_gemm {
     float *colsum;                       /* optional [batch1, n]: colsum[z1, j] = sum over z0 and rows of the stored C
                                             (the bias gradient np.sum(dy, axis=0), mlp.py:34 / attentions.py:190-197,
                                             taken in the producing GEMM's epilogue; fixed summation order) */
+    float *bsum;                         /* optional [n]: bsum[j] = sum over k of B[k, j] -- the column sums of the
+                                            second operand of a weight-gradient product x^T dy, i.e. the bias gradient
+                                            that goes with it (mlp.py:34-35, attentions.py:129-135,190-197), taken from
+                                            the B tiles the GEMM stages anyway.  Needs trans_b = 0, batch0 = batch1 = 1. */
+    float *asum;                         /* optional [m]: asum[i] = sum over k of A[k, i] for a transposed A (trans_a = 1,
+                                            stored [k, m]): the same for products written dproj^T x, whose bias gradient
+                                            sums the FIRST operand (attentions.py:167-197).  Not together with bsum. */
 } npm_gemm;
 
 int npm_sgemm(const npm_gemm *g);

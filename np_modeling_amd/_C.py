@@ -37,6 +37,8 @@ class npm_gemm(C.Structure):
         ('split_k', C.c_int32),
         ('rowvec', C.c_void_p),
         ('colsum', C.c_void_p),
+        ('bsum', C.c_void_p),
+        ('asum', C.c_void_p),
     ]
 
 

@@ -38,6 +38,8 @@ struct GemmArgs {
     int batch1;
     int tiles_m, tiles_n, splits, k_per_split;
     int group_m;
+    float *ksum;     // optional [splits][N or M] partial sums over k of B (ksum_op 1) or A (2): TN layout, batch 1
+    int ksum_op;
     long long *trace; // diagnostics: 8 words per block (hw id, xcc id, 4 s_memtime stamps) or null
     int wide;        // 128 x 256 block tile (2 x 4 waves) instead of 128 x 128
     int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers, 8 skip the epilogue
@@ -153,9 +155,16 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // WM x WN wavefronts per block, each owning 64 x 64 of the (64 WM) x (64 WN) block tile.
 //   2 x 2 (256 threads, 4 blocks/CU): the default.   2 x 4 (512 threads, 2 blocks/CU): 128 x 256 tile --
 //   each activation panel is re-read by half as many column tiles (less L2-miss traffic per FLOP).
-template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2>
+// KSUM (TN layout only): 1 = also sum the B tiles over k (the column sums of B [K, N]), 2 = the A tiles (the
+// column sums of A [K, M]) -- the bias gradient that goes with a weight gradient x^T dy (mlp.py:34-35) or
+// dproj^T x (attentions.py:167-188), instead of a separate pass over dy.  The tiles_m (tiles_n) blocks that stage
+// the same B (A) tile split its 16 k rows between them, so every block carries the same small load (a launch of
+// co-resident blocks lasts as long as its slowest block): one or two LDS reads and adds per thread and K tile.
+// Partial sums: one row per (split, sharing block); the host adds the rows.
+template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2, int KSUM = 0>
 __global__ void __launch_bounds__(64 * WM * WN, (WITH_COLSUM ? 12 : 16) / (WM * WN))   // 16 (12) waves per CU
 sgemm_glds_kernel(const GemmArgs p) {
+    static_assert(!KSUM || (!A_KMAJ && !B_KMAJ && WM == 2 && WN == 2 && !WITH_COLSUM), "KSUM: TN layout, 128 x 128 tile");
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
     constexpr int A_PW = 4 / WN, B_PW = 4 / WM;          // 1 KiB DMA pieces per wave and K tile
@@ -219,6 +228,11 @@ sgemm_glds_kernel(const GemmArgs p) {
     zero_acc(acc);
     const int arow = wm * 64 + l32;
     const int brow = wn * 64 + l32;
+    const int ks_idx = KSUM == 1 ? tm : tn;                       // which of the blocks sharing this operand tile
+    const int ks_share = KSUM == 1 ? p.tiles_m : p.tiles_n;
+    const bool do_ksum = KSUM && z == 0 && ks_idx < GK;
+    const int ks_row0 = ks_idx + (wave >> 1) * ks_share;          // this thread's k rows: ks_row0 + 2 j ks_share
+    float ks_acc = 0.f;                                           // column tid & 127
 
     long long t_start = 0, t_first = 0, t_loop = 0, r_start = 0;
     if (p.trace) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
@@ -231,7 +245,21 @@ sgemm_glds_kernel(const GemmArgs p) {
         if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * STAGE;
         const float *sB = sA + A_TILE;
+        if (KSUM && do_ksum) {
+            const float *st = (KSUM == 1 ? sB : sA) + (tid & 127);          // both tiles are [16 k][128] here
+            for (int r = ks_row0; r < GK; r += 2 * ks_share) ks_acc += st[r * 128];
+        }
         mma_tile16<A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc);
+    }
+    if (KSUM && do_ksum) {       // the two thread halves -> one sum per column; the stage buffers are free after a barrier
+        __syncthreads();
+        smem[tid] = ks_acc;
+        __syncthreads();
+        if (tid < 128) {
+            const int extent = KSUM == 1 ? p.N : p.M, at = (KSUM == 1 ? n0 : m0) + tid;
+            const int rows = min(ks_share, GK);
+            if (at < extent) p.ksum[((long)split * rows + ks_idx) * extent + at] = smem[tid] + smem[tid + 128];
+        }
     }
 
     if (p.trace) t_loop = __builtin_amdgcn_s_memtime();
@@ -283,7 +311,12 @@ inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 template <bool A_KMAJ, bool B_KMAJ>
 void launch(const GemmArgs &a, bool vec, bool dma, int grid, hipStream_t stream) {
-    if (dma && a.wide)
+    if (dma && a.ksum) {
+        if constexpr (!A_KMAJ && !B_KMAJ) {
+            if (a.ksum_op == 1) hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+            else hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 2>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+        }
+    } else if (dma && a.wide)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false, 2, 4>), dim3(grid), dim3(512), 0, stream, a);
     else if (dma && a.e.cs)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
@@ -384,8 +417,14 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     vec = vec && (a_kmaj ? g->k % 4 == 0 : g->m % 4 == 0);
     vec = vec && (b_kmaj ? g->k % 4 == 0 : g->n % 4 == 0);
     const bool want_colsum = g->colsum != nullptr;
+    const bool want_bsum = g->bsum != nullptr, want_asum = g->asum != nullptr;
+    NPM_ARG(!want_bsum || (!b_kmaj && g->batch0 == 1 && g->batch1 == 1 && !want_colsum));   // B stored [K, N]
+    NPM_ARG(!want_asum || (!a_kmaj && g->batch0 == 1 && g->batch1 == 1 && !want_colsum && !want_bsum));   // A stored [K, M]
+    const bool want_ksum = want_bsum || want_asum;
+    const int ksum_len = want_bsum ? g->n : g->m;
+    float *ksum_out = want_bsum ? g->bsum : g->asum;
     // 128 x 256 tile: only where it divides N and the LDS-DMA kernel will run (spans re-checked below)
-    const int tile_n = ((g_wide_tile == 1 || (g_wide_tile == 2 && a_kmaj) || (g_wide_tile == 3 && a_kmaj && b_kmaj)) && g_pipe == 2 && vec && g->k % GK == 0 && g->n % 256 == 0 && !want_colsum &&
+    const int tile_n = ((g_wide_tile == 1 || (g_wide_tile == 2 && a_kmaj) || (g_wide_tile == 3 && a_kmaj && b_kmaj)) && g_pipe == 2 && vec && g->k % GK == 0 && g->n % 256 == 0 && !want_colsum && !want_ksum &&
                         (long)256 * g->ldb * 4 < (1L << 30)) ? 256 : BN;
     a.wide = tile_n == 256;
     a.tiles_m = (g->m + BM - 1) / BM;
@@ -451,6 +490,16 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (a.wide && !(dma && a.e.buf_ok))
         return npm::fail(NPM_E_UNSUPPORTED, "npm_sgemm: operand spans too large for the 128x256 tile (disable NPM_TUNE_GEMM_WIDE_TILE)");
     const bool dma_path = dma && a.e.buf_ok;
+    // Column sums of B beside a TN product: in the kernel when the LDS-DMA path runs, else a pass over B.
+    npm::Scratch bs_part;
+    const bool ksum_fused = want_ksum && dma_path && !a_kmaj && !b_kmaj && g->k > 0;
+    const long ksum_rows = (long)splits * std::min(want_bsum ? a.tiles_m : a.tiles_n, GK);
+    if (ksum_fused) {
+        a.ksum_op = want_bsum ? 1 : 2;
+        int rc = bs_part.alloc(sizeof(float) * (size_t)ksum_rows * ksum_len);
+        if (rc) return rc;
+        a.ksum = (float *)bs_part.ptr;
+    }
     npm::Scratch cs_part;
     const long cs_rows = (long)g->batch0 * a.tiles_m * 2, cs_cols = (long)g->batch1 * g->n;
     if (want_colsum && dma_path) {
@@ -463,6 +512,13 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     else launch<false, false>(a, vec, dma, (int)grid, stream);
     NPM_CHECK_LAUNCH();
 
+    if (want_ksum) {
+        int rc = NPM_OK;
+        if (!ksum_fused) rc = want_bsum ? npm::colsum_launch(g->b, g->bsum, g->k, g->n, g->ldb)
+                                        : npm::colsum_launch(g->a, g->asum, g->k, g->m, g->lda);
+        else rc = npm::colsum_launch(a.ksum, ksum_out, ksum_rows, ksum_len, ksum_len);
+        if (rc) return rc;
+    }
     if (want_colsum) {
         if (a.e.cs) return npm::colsum_launch(a.e.cs, g->colsum, cs_rows, cs_cols, cs_cols);
         // fallback: one strided pass per z1 over the stored C (batches must be row-contiguous)

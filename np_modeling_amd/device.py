@@ -382,6 +382,7 @@ class Event:
 # ---- kernel wrappers -------------------------------------------------------------------------
 FUSE_COLSUM = os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switches (see gemm, attentions.py)
 FUSE_SOFTMAX_BWD = os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
+FUSE_BSUM = os.environ.get('NPM_FUSE_BSUM', '1') != '0'          # bias gradient inside the weight-gradient GEMM
 PACK_QKV = os.environ.get('NPM_PACK_QKV', '1') != '0'
 
 class KernelTimer:
@@ -447,12 +448,16 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
          batch: Tuple[int, int] = (1, 1), alpha: float = 1.0, bias: Optional[DeviceArray] = None,
          residual: Optional[Mat] = None, relu_save: Optional[Mat] = None, relu_mask: Optional[Mat] = None,
          split_k: int = 0, colsum_out: Optional[DeviceArray] = None,
-         softmax_bwd: Optional[Tuple[Mat, DeviceArray]] = None) -> None:
+         softmax_bwd: Optional[Tuple[Mat, DeviceArray]] = None,
+         bsum_out: Optional[DeviceArray] = None, asum_out: Optional[DeviceArray] = None) -> None:
     """C = epilogue(alpha * op(A) @ op(B)); see include/npm_hip.h ``npm_sgemm``.
     ``colsum_out`` ([batch1, n]) receives the column sums of the stored C (a bias gradient
     taken in the producing GEMM's epilogue instead of a separate pass over C).
     ``softmax_bwd=(P, delta)``: C = alpha * P * (A @ B - delta[row]) -- the softmax backward with its
-    row term precomputed (:func:`attn_rowdot`), fused into the GEMM that produces dP."""
+    row term precomputed (:func:`attn_rowdot`), fused into the GEMM that produces dP.
+    ``bsum_out`` ([n]) receives the column sums of B ([k, n], not transposed): the bias gradient that goes
+    with a weight gradient x^T @ dy, taken from the dy tiles that GEMM stages anyway; ``asum_out`` ([m]) the
+    column sums of a transposed A ([k, m]) for products written dproj^T @ x."""
     g = _C.npm_gemm()
     g.trans_a, g.trans_b = int(trans_a), int(trans_b)
     g.m, g.n, g.k = int(m), int(n), int(k)
@@ -482,12 +487,24 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
     g.split_k = int(split_k)
     fuse = colsum_out is not None and FUSE_COLSUM
     g.colsum = colsum_out.ptr if fuse else None
+    fuse_b = bsum_out is not None and FUSE_BSUM
+    g.bsum = bsum_out.ptr if fuse_b else None
+    fuse_a = asum_out is not None and FUSE_BSUM
+    g.asum = asum_out.ptr if fuse_a else None
     layout = 'TN' if trans_a else ('NT' if trans_b else 'NN')
     nb = batch[0] * batch[1]
     unique = 4.0 * nb * (m * k + k * n + m * n * (1 + (residual is not None) + (relu_save is not None) +
                                                   (relu_mask is not None) + (softmax_bwd is not None)))
     with _timed('sgemm_' + layout, flops=2.0 * m * n * k * nb, nbytes=unique):
         _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
+    if bsum_out is not None and not fuse_b:      # A/B switch: separate pass over B
+        assert batch == (1, 1) and not trans_b
+        with _timed('colsum', nbytes=4.0 * k * n):
+            _C.check(_C.lib().npm_colsum(b.ptr, bsum_out.ptr, k, n, b.ld), 'npm_colsum')
+    if asum_out is not None and not fuse_a:
+        assert batch == (1, 1) and trans_a
+        with _timed('colsum', nbytes=4.0 * k * m):
+            _C.check(_C.lib().npm_colsum(a.ptr, asum_out.ptr, k, m, a.ld), 'npm_colsum')
     if colsum_out is not None and not fuse:      # A/B switch: separate pass over the stored C
         assert c.ld == n * batch[1] and (batch[1] == 1 or c.s1 == n), 'unfused colsum needs row-contiguous head slices'
         colsum(DeviceArray([1], c._keep._buf, c.ptr), m * batch[0], n * batch[1], out=colsum_out)

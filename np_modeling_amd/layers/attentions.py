@@ -173,10 +173,10 @@ class MultiHeadAttention(layer.StatefulLayer):
         m_q, m_kv = b * sq, b * skv
 
         # output projection (attentions.py:129-136)
+        # dbo = sum over (batch, position) of dy: taken from the dy tiles of the weight-gradient GEMM
         dbo = scope.take([f])
-        D.colsum(dy, m_q, f, out=dbo)
         dwo = scope.take(wo.shape)
-        D.gemm(f, h * dv, m_q, Mat(dy, f), Mat(ctx, h * dv), Mat(dwo, h * dv), trans_a=True)      # dy^T ctx
+        D.gemm(f, h * dv, m_q, Mat(dy, f), Mat(ctx, h * dv), Mat(dwo, h * dv), trans_a=True, asum_out=dbo)   # dy^T ctx
         dctx = D.empty([b, sq, h, dv])
         D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))                    # dy wo
 
@@ -197,8 +197,8 @@ class MultiHeadAttention(layer.StatefulLayer):
             D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
                    Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))            # dctx_h v_h^T
             D.softmax_bwd(scores, datt, self._scale, out=datt)
-        # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): column sums taken in
-        # the epilogues of the GEMMs that produce them
+        # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): taken from the dq/dk/dv
+        # tiles of the in-projection weight-gradient GEMMs below
         if packed:      # gradients of the packed parameters and of q/k/v live in packed buffers too
             dw_all, db_all = scope.take([3, h, dk, f]), scope.take([3, h, dk])
             dwq, dwk, dwv = (dw_all.flat_view(i * h * dk * f, [h, dk, f]) for i in range(3))
@@ -212,21 +212,21 @@ class MultiHeadAttention(layer.StatefulLayer):
             dq, dk_, dv_ = D.empty([b, sq, h, dk]), D.empty([b, skv, h, dk]), D.empty([b, skv, h, dv])
             gq, gk, gv = h * dk, h * dk, h * dv
         D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
-               Mat(dv_, gv, skv * gv, dv), trans_a=True, batch=(b, h), colsum_out=dbv)            # P_h^T dctx_h
+               Mat(dv_, gv, skv * gv, dv), trans_a=True, batch=(b, h))                            # P_h^T dctx_h
 
         # Q K^T (attentions.py:161-162)
         D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, pk, skv * pk, dk),
-               Mat(dq, gq, sq * gq, dk), batch=(b, h), colsum_out=dbq)                            # datt_h k_h
+               Mat(dq, gq, sq * gq, dk), batch=(b, h))                                            # datt_h k_h
         D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, pq, sq * pq, dk),
-               Mat(dk_, gk, skv * gk, dk), trans_a=True, batch=(b, h), colsum_out=dbk)            # datt_h^T q_h
+               Mat(dk_, gk, skv * gk, dk), trans_a=True, batch=(b, h))                            # datt_h^T q_h
 
         # in-projections (attentions.py:167-188): dw = dproj^T x ; dx = dproj w
         if packed:
-            D.gemm(3 * f, f, m_q, Mat(dqkv, 3 * f), Mat(query, f), Mat(dw_all, f), trans_a=True)
+            D.gemm(3 * f, f, m_q, Mat(dqkv, 3 * f), Mat(query, f), Mat(dw_all, f), trans_a=True, asum_out=db_all)
         else:
-            D.gemm(h * dk, f, m_q, Mat(dq, gq), Mat(query, f), Mat(dwq, f), trans_a=True)
-            D.gemm(h * dk, f, m_kv, Mat(dk_, gk), Mat(key, f), Mat(dwk, f), trans_a=True)
-            D.gemm(h * dv, fv, m_kv, Mat(dv_, gv), Mat(value, fv), Mat(dwv, fv), trans_a=True)
+            D.gemm(h * dk, f, m_q, Mat(dq, gq), Mat(query, f), Mat(dwq, f), trans_a=True, asum_out=dbq)
+            D.gemm(h * dk, f, m_kv, Mat(dk_, gk), Mat(key, f), Mat(dwk, f), trans_a=True, asum_out=dbk)
+            D.gemm(h * dv, fv, m_kv, Mat(dv_, gv), Mat(value, fv), Mat(dwv, fv), trans_a=True, asum_out=dbv)
         # every parameter gradient of this layer now exists: start exchanging them (data parallel) under
         # the remaining input-gradient GEMMs
         scope.flush()

@@ -67,11 +67,12 @@ class Linear(layer.StatefulLayer):
         # dy: [m, n]; x: [m, k] -- 2-D only, like the reference (mlp.py:33)
         assert dy.shape == (x.shape[0], n), f'{dy.shape} vs {(x.shape[0], n)}'
         m = dy.shape[0]
-        if db is None:
+        have_db = db is not None
+        if not have_db:
             db = scope.take([n])
-            D.colsum(dy, m, n, out=db)
         dw = scope.take([k, n])
-        D.gemm(k, n, m, Mat(x, k), Mat(dy, n), Mat(dw, n), trans_a=True)          # x^T @ dy
+        # x^T @ dy; the same GEMM sums its dy tiles over the batch: db = np.sum(dy, axis=0) (mlp.py:34)
+        D.gemm(k, n, m, Mat(x, k), Mat(dy, n), Mat(dw, n), trans_a=True, bsum_out=None if have_db else db)
         dx = None
         if need_dx:
             dx = D.empty([m, k])

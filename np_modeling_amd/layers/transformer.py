@@ -111,16 +111,15 @@ class TransformerEncoder(layer.Layer):
         if not self._norm_first:
             dy = self._norm2._backward_impl(dy, optimizer_, scope)
         dskip = dy
-        # dense2: dx masked by dense1's ReLU (activations.py:19) in the GEMM epilogue, which also takes
-        # the column sums of the masked dx = dense1's bias gradient (mlp.py:34)
-        db1 = scope.take([lin1._output_units])
-        dh = lin2._backward_impl(dy, optimizer_, scope, relu_mask_pre=pre1, dx_colsum_out=db1)
+        # dense2: dx masked by dense1's ReLU (activations.py:19) in the GEMM epilogue; dense1's bias gradient
+        # (the column sums of that masked dx, mlp.py:34) comes out of dense1's weight-gradient GEMM
+        dh = lin2._backward_impl(dy, optimizer_, scope, relu_mask_pre=pre1)
         scope.flush()
         if self._norm_first:
-            dy = lin1._backward_impl(dh, optimizer_, scope, db=db1)
+            dy = lin1._backward_impl(dh, optimizer_, scope)
             dy = self._norm2._backward_impl(dy, optimizer_, scope, residual=dskip)     # dy += dskip
         else:
-            dy = lin1._backward_impl(dh, optimizer_, scope, residual=dskip, db=db1)    # dy += dskip
+            dy = lin1._backward_impl(dh, optimizer_, scope, residual=dskip)            # dy += dskip
         scope.flush()
         dy = dy.reshape(batch, seq_len_q, features)
         if not self._norm_first:

@@ -147,6 +147,12 @@ class HostSim:
                 sums[z1] += _mat(g.c + oc, g.m, g.n, g.ldc).astype(np.float64).sum(axis=0)
         if g.colsum:
             _vec(g.colsum, g.batch1 * g.n)[:] = sums.ravel()
+        if g.bsum:
+            assert not g.trans_b and g.batch0 == 1 and g.batch1 == 1
+            _vec(g.bsum, g.n)[:] = _mat(g.b, g.k, g.n, g.ldb).astype(np.float64).sum(axis=0)
+        if g.asum:
+            assert g.trans_a and g.batch0 == 1 and g.batch1 == 1 and not g.bsum
+            _vec(g.asum, g.m)[:] = _mat(g.a, g.k, g.m, g.lda).astype(np.float64).sum(axis=0)
         return 0
 
     # ---- elementwise ------------------------------------------------------------------------

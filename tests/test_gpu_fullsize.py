@@ -96,7 +96,13 @@ def test_encoder_full_size_slices_and_additivity(npm):
         enc(D.from_host(dy[lo:hi]), backprop=True, optimizer_=rec)
         for k, v in rec.grads.items():
             acc[k] = acc.get(k, 0) + np.asarray(v).astype(np.float64)
+    bq_scale = max(np.abs(v).max() for k, v in full.items() if k[1] == '_bq')
     for k in full:
+        if k[1] == '_bk':
+            # the key-bias gradient is exactly zero in real arithmetic (every row of datt sums to 0, so adding a
+            # constant to all keys changes nothing): what is stored is rounding noise, held against dbq's scale
+            assert np.abs(full[k]).max() < 1e-4 * bq_scale and np.abs(acc[k]).max() < 1e-4 * bq_scale
+            continue
         assert_close(full[k], acc[k], tol=2e-5, what=str(k[:2]))
 
     # (3) attention probabilities (last run: half batch, 0.5 M rows of 512): every row sums to 1 (P 1 = 1 by GEMM)
@@ -191,4 +197,8 @@ def test_mha_c4_slice(npm):
         for k, v in r.grads.items():
             acc[k[1]] = acc.get(k[1], 0) + np.asarray(v).astype(np.float64)
     for k in full:
+        if k == '_bk':      # exactly zero in real arithmetic (rows of datt sum to 0): rounding noise, held against dbq's scale
+            bound = 1e-4 * np.abs(full['_bq']).max()
+            assert np.abs(full[k]).max() < bound and np.abs(acc[k]).max() < bound
+            continue
         assert_close(full[k], acc[k], tol=2e-5, what=k)

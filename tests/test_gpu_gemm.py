@@ -202,6 +202,38 @@ def test_colsum_in_epilogue(D, m, n, k, batch):
     assert_close(sums, c.numpy().astype(np.float64).sum(axis=(0, 1)), tol=3e-6)
 
 
+@pytest.mark.parametrize('m,n,k', [(128, 128, 64), (256, 384, 4096),      # LDS-DMA path, one split and split-K
+                                   (1024, 256, 32768),                     # many splits: 8 tile rows x 2 tile columns
+                                   (200, 72, 1040), (130, 20, 33), (5, 3, 7), (64, 640, 16), (384, 16, 2048)])
+@pytest.mark.parametrize('which', ['bsum', 'asum'])
+def test_bias_gradient_beside_weight_gradient(D, m, n, k, which):
+    """dw = x^T dy with db = sum_k dy[k, :] (bsum: mlp.py:34-35) or sum_k of the first operand
+    (asum: attentions.py:167-197) taken from the operand tiles of the same GEMM; fallback shapes too."""
+    rng = np.random.default_rng(m * 31 + n * 7 + k)
+    a = rng.standard_normal((k, m)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    c = D.full([m, n], np.nan)
+    length = n if which == 'bsum' else m
+    sums = D.from_host(np.full(length + 2, 55.0, dtype=np.float32))         # guard words either side
+    out = sums.flat_view(1, [length])
+    D.gemm(m, n, k, D.Mat(D.from_host(a), m), D.Mat(D.from_host(b), n), D.Mat(c, n), trans_a=True,
+           **{which + '_out': out})
+    assert_close(c, _ref(a, b, True, False), tol=3e-6)
+    src = b if which == 'bsum' else a
+    host = sums.numpy()
+    assert host[0] == 55.0 and host[-1] == 55.0
+    assert_close(host[1:-1], src.astype(np.float64).sum(axis=0), tol=3e-6)
+
+
+def test_bias_gradient_arguments(D):
+    from np_modeling_amd import _C
+    a, b, c, s = D.zeros([64, 64]), D.zeros([64, 64]), D.empty([64, 64]), D.empty([64])
+    with pytest.raises(_C.NpmError):          # bsum needs B stored [k, n]
+        D.gemm(64, 64, 64, D.Mat(a, 64), D.Mat(b, 64), D.Mat(c, 64), trans_b=True, bsum_out=s)
+    with pytest.raises(_C.NpmError):          # asum needs A stored [k, m]
+        D.gemm(64, 64, 64, D.Mat(a, 64), D.Mat(b, 64), D.Mat(c, 64), asum_out=s)
+
+
 @pytest.mark.parametrize('bsz,h,sq,skv,d', [(2, 4, 64, 128, 16), (3, 2, 40, 24, 12), (1, 8, 512, 512, 128), (2, 3, 33, 17, 5)])
 def test_softmax_backward_fused_into_the_dp_gemm(D, bsz, h, sq, skv, d):
     """datt = scale * P * (dctx v^T - rowdot(dctx, ctx)) in one GEMM epilogue equals the reference's
