@@ -123,6 +123,7 @@ enum {
     NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
     NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, -1 unbalanced ceil(3 CUs / tiles) */
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */
+    NPM_TUNE_GEMM_MATH = 10,         /* 0 exact-f32 MFMA; 1 fp32 products as six bf16 MFMAs of a three-way operand split */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);

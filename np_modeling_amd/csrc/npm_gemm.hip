@@ -40,6 +40,7 @@ struct GemmArgs {
     int group_m;
     float *ksum;     // optional [splits][N or M] partial sums over k of B (ksum_op 1) or A (2): TN layout, batch 1
     int ksum_op;
+    int math;        // 0 exact-f32 MFMA, 1 three-way bf16 split on the bf16 MFMA (NPM_TUNE_GEMM_MATH)
     long long *trace; // diagnostics: 8 words per block (hw id, xcc id, 4 s_memtime stamps) or null
     int wide;        // 128 x 256 block tile (2 x 4 waves) instead of 128 x 128
     int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers, 8 skip the epilogue
@@ -51,6 +52,7 @@ int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline whe
 int g_group_m = 8;
 int g_ablate = 0;
 int g_wave_prio = 0;               // NPM_TUNE_GEMM_WAVE_PRIO
+int g_math = 0;                    // NPM_TUNE_GEMM_MATH
 int g_wide_tile = 0;               // NPM_TUNE_GEMM_WIDE_TILE: 128 x 256 tile where n % 256 == 0: 0 never, 1 always, 2 NN/NT, 3 NT only
 long long *g_trace = nullptr;    // diagnostics: per-block timeline stamps (npm_debug_gemm_trace)
 int g_buf_epilogue = 1;
@@ -161,8 +163,8 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // the same B (A) tile split its 16 k rows between them, so every block carries the same small load (a launch of
 // co-resident blocks lasts as long as its slowest block): one or two LDS reads and adds per thread and K tile.
 // Partial sums: one row per (split, sharing block); the host adds the rows.
-template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2, int KSUM = 0>
-__global__ void __launch_bounds__(64 * WM * WN, (WITH_COLSUM ? 12 : 16) / (WM * WN))   // 16 (12) waves per CU
+template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2, int KSUM = 0, int MATH = 0>
+__global__ void __launch_bounds__(64 * WM * WN, (MATH == 2 ? 8 : (WITH_COLSUM || MATH) ? 12 : 16) / (WM * WN))   // 16 (12, 8) waves per CU
 sgemm_glds_kernel(const GemmArgs p) {
     static_assert(!KSUM || (!A_KMAJ && !B_KMAJ && WM == 2 && WN == 2 && !WITH_COLSUM), "KSUM: TN layout, 128 x 128 tile");
     constexpr int TM = 64 * WM, TN = 64 * WN;
@@ -226,6 +228,8 @@ sgemm_glds_kernel(const GemmArgs p) {
 
     f32x16 acc[2][2];
     zero_acc(acc);
+    f32x16 small[MATH == 2 ? 2 : 1][MATH == 2 ? 2 : 1];      // MATH 2: the split's small terms, added once at the end
+    if (MATH == 2) zero_acc(reinterpret_cast<f32x16 (&)[2][2]>(small));
     const int arow = wm * 64 + l32;
     const int brow = wn * 64 + l32;
     const int ks_idx = KSUM == 1 ? tm : tn;                       // which of the blocks sharing this operand tile
@@ -249,7 +253,13 @@ sgemm_glds_kernel(const GemmArgs p) {
             const float *st = (KSUM == 1 ? sB : sA) + (tid & 127);          // both tiles are [16 k][128] here
             for (int r = ks_row0; r < GK; r += 2 * ks_share) ks_acc += st[r * 128];
         }
-        mma_tile16<A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc);
+        mma_tile16_math<MATH, A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
+    }
+    if (MATH == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] += reinterpret_cast<f32x16 (&)[2][2]>(small)[i][j];
     }
     if (KSUM && do_ksum) {       // the two thread halves -> one sum per column; the stage buffers are free after a barrier
         __syncthreads();
@@ -313,10 +323,22 @@ template <bool A_KMAJ, bool B_KMAJ>
 void launch(const GemmArgs &a, bool vec, bool dma, int grid, hipStream_t stream) {
     if (dma && a.ksum) {
         if constexpr (!A_KMAJ && !B_KMAJ) {
-            if (a.ksum_op == 1) hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
-            else hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 2>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+            if (a.math == 1) {
+                if (a.ksum_op == 1) hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 1, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+                else hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 2, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+            } else if (a.math == 2) {
+                if (a.ksum_op == 1) hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 1, 2>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+                else hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 2, 2>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+            } else {
+                if (a.ksum_op == 1) hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+                else hipLaunchKernelGGL((sgemm_glds_kernel<false, false, false, 2, 2, 2>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+            }
         }
-    } else if (dma && a.wide)
+    } else if (dma && a.math == 1 && !a.wide && !a.e.cs)
+        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false, 2, 2, 0, 1>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    else if (dma && a.math == 2 && !a.wide && !a.e.cs)
+        hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false, 2, 2, 0, 2>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    else if (dma && a.wide)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false, 2, 4>), dim3(grid), dim3(512), 0, stream, a);
     else if (dma && a.e.cs)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
@@ -377,6 +399,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         case NPM_TUNE_CONV_WGRAD_BLOCKS: return npm_conv_set_wgrad_blocks(value);
+        case NPM_TUNE_GEMM_MATH: g_math = value; return NPM_OK;
         case NPM_TUNE_GEMM_WAVE_PRIO: g_wave_prio = value; return npm_conv_set_wave_prio(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
@@ -446,6 +469,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.group_m = g_group_m;
     a.ablate = g_ablate;
     a.e.prio = g_wave_prio;
+    a.math = g_math;
     a.trace = g_trace;
 
     const long batch = (long)g->batch0 * g->batch1;
