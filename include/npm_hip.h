@@ -123,10 +123,25 @@ enum {
     NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
     NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, -1 unbalanced ceil(3 CUs / tiles) */
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */
-    NPM_TUNE_GEMM_MATH = 10,         /* 0 exact-f32 MFMA; 1 fp32 products as six bf16 MFMAs of a three-way operand split */
+    NPM_TUNE_GEMM_MATH = 10,         /* same as npm_set_math */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);
+
+/* Arithmetic of the matrix products (GEMM and convolution kernels).  Inputs, outputs and accumulators are fp32 in
+ * every mode; what changes is the instruction that forms the products:
+ *   NPM_MATH_F32          v_mfma_f32_32x32x2_f32: exact fp32 products, bit-equal to a k-ordered fmaf chain (default).
+ *   NPM_MATH_BF16X3       each operand is split in registers into three bf16 parts (hi rounded, mid, lo: 24 mantissa
+ *                         bits, the parts add up to the fp32 value) and the product is formed as the six largest
+ *                         cross terms on v_mfma_f32_32x32x16_bf16, the five small terms in accumulators of their own.
+ *                         Error against fp64 is at or below the f32 mode's (tools/math_bias.py);
+ *                         results are NOT bit-equal to the f32 mode.
+ *   NPM_MATH_BF16X3_FAST  the same six terms into one accumulator: fewer registers, faster; the matrix pipe cuts
+ *                         small addends against a large accumulator, which leaves a bias of about -0.5 ulp per
+ *                         4096 accumulated terms (visible in column checksums, not per element). */
+enum { NPM_MATH_F32 = 0, NPM_MATH_BF16X3_FAST = 1, NPM_MATH_BF16X3 = 2 };
+int npm_set_math(int mode);
+int npm_get_math(void);
 /* Diagnostics: when buf != NULL every block of the LDS-DMA GEMM writes 8 words (hardware id, XCC id, s_memtime at
  * start / first tile landed / loop end / after the epilogue stores) to buf[blockIdx*8 ..]; NULL switches it off. */
 int npm_debug_gemm_trace(long long *buf);

@@ -78,6 +78,8 @@ SIGNATURES = {
     'npm_event_elapsed_ms': [_P, _P, C.POINTER(_F)],
     'npm_sgemm': [C.POINTER(npm_gemm)],
     'npm_set_tuning': [C.c_int, C.c_int],
+    'npm_set_math': [C.c_int],
+    'npm_get_math': [],
     'npm_debug_gemm_trace': [_P],
     'npm_relu_fwd': [_P, _P, _SZ],
     'npm_relu_bwd': [_P, _P, _P, _SZ],
@@ -189,7 +191,25 @@ def lib():
         for item in filter(None, os.environ.get('NPM_TUNE', '').split(',')):     # e.g. NPM_TUNE=0=2 (A/B experiments)
             knob, value = item.split('=')
             check(_LIB.npm_set_tuning(int(knob), int(value)), 'npm_set_tuning')
+        if os.environ.get('NPM_MATH'):
+            set_math(os.environ['NPM_MATH'])
     return _LIB
+
+
+MATH_MODES = {'f32': 0, 'bf16x3_fast': 1, 'bf16x3': 2}      # include/npm_hip.h NPM_MATH_*
+
+
+def set_math(mode: str) -> None:
+    """Arithmetic of the matrix products: 'f32' (exact-fp32 MFMA, default), 'bf16x3' (three-way bf16 operand split
+    on the bf16 matrix pipe, fp32-class error) or 'bf16x3_fast' (same, one accumulator); include/npm_hip.h."""
+    if mode not in MATH_MODES:
+        raise ValueError(f'unknown math mode {mode!r}: expected one of {sorted(MATH_MODES)}')
+    check(lib().npm_set_math(MATH_MODES[mode]), 'npm_set_math')
+
+
+def get_math() -> str:
+    value = lib().npm_get_math()
+    return next(name for name, v in MATH_MODES.items() if v == value)
 
 
 def comm_lib():

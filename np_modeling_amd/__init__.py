@@ -19,6 +19,7 @@ __version__ = '0.1.0'
 from np_modeling_amd import _C, device, parallel          # noqa: E402,F401
 from np_modeling_amd import optimizer, layers, loss, train  # noqa: E402,F401
 from np_modeling_amd.device import DeviceArray, as_device, synchronize  # noqa: E402,F401
+from np_modeling_amd._C import set_math, get_math  # noqa: E402,F401
 
 
 def install(include_support_modules: bool = False) -> None:

@@ -214,8 +214,8 @@ constexpr int OOB_OFFSET = 0x7FFFFFFF;
 // forward / grad_x: requires C % 16 == 0 (a 16-deep K tile lies inside ONE tap), N % 4 == 0.
 // TALL = false: 128 x 128 block tile, waves 2 x 2.   TALL = true: 256 x 64 block tile, waves 4 x 1 --
 // for N <= 64 (grad_x of a layer with <= 64 input channels) a 128-wide tile would idle half the MFMAs.
-template <bool TALL>
-__global__ void __launch_bounds__(NTHREADS, 4)
+template <bool TALL, int MATH = 0>
+__global__ void __launch_bounds__(NTHREADS, MATH == 2 ? 2 : MATH ? 3 : 4)
 conv_fwd_glds_kernel(const ConvArgs p) {
     constexpr int TM = TALL ? 256 : 128, TN = TALL ? 64 : 128;
     constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
@@ -284,6 +284,8 @@ conv_fwd_glds_kernel(const ConvArgs p) {
 
     f32x16 acc[2][2];
     zero_acc(acc);
+    f32x16 small[MATH == 2 ? 2 : 1][MATH == 2 ? 2 : 1];      // split-bf16 math, mode 2: the small terms (npm_mfma_tile.h)
+    if (MATH == 2) zero_acc(reinterpret_cast<f32x16 (&)[2][2]>(small));
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
     if (nkt > 0) NPM_CONV_ISSUE(0, 0);
     prio_low(p.e.prio & 1);
@@ -291,16 +293,23 @@ conv_fwd_glds_kernel(const ConvArgs p) {
         __syncthreads();
         if (kt + 1 < nkt) NPM_CONV_ISSUE(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * STAGE;
-        mma_tile16<true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc);
+        mma_tile16_math<MATH, true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
     }
 #undef NPM_CONV_ISSUE
+    if (MATH == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] += reinterpret_cast<f32x16 (&)[2][2]>(small)[i][j];
+    }
     prio_high(p.e.prio & 2);
     if (p.e.buf_ok) write_tile_buf(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
     else write_tile(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
 
 // grad_w: A(k = pixel, m' = (tap, c)) gathered M-major; requires C % 4 == 0, pixels % 16 == 0.
-__global__ void __launch_bounds__(NTHREADS, 4)
+template <int MATH = 0>
+__global__ void __launch_bounds__(NTHREADS, MATH == 2 ? 2 : MATH ? 3 : 4)
 conv_wgrad_glds_kernel(const ConvArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2 * G_STAGE];
     prio_high(p.e.prio & 1);
@@ -365,6 +374,8 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
 
     f32x16 acc[2][2];
     zero_acc(acc);
+    f32x16 small[MATH == 2 ? 2 : 1][MATH == 2 ? 2 : 1];
+    if (MATH == 2) zero_acc(reinterpret_cast<f32x16 (&)[2][2]>(small));
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
     // k*k*C0 is rarely a multiple of 128: waves whose 64 rows lie past M only feed the DMA pipeline
     const bool wave_has_rows = m0 + wm * 64 < p.M && n0 + wn * 64 < p.N;
@@ -374,7 +385,13 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
         __syncthreads();
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
-        if (wave_has_rows) mma_tile16<false, false>(sA, sA + G_TILE, arow, brow, half, acc);
+        if (wave_has_rows) mma_tile16_math<MATH, false, false>(sA, sA + G_TILE, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
+    }
+    if (MATH == 2) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][j] += reinterpret_cast<f32x16 (&)[2][2]>(small)[i][j];
     }
     prio_high(p.e.prio & 2);
     Epilogue e = p.e;
@@ -401,6 +418,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 
 int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
 int g_conv_wave_prio = 0;   // NPM_TUNE_GEMM_WAVE_PRIO
+int g_conv_math = 0;        // NPM_TUNE_GEMM_MATH
 int g_wgrad_blocks_per_cu = 0;   // NPM_TUNE_CONV_WGRAD_BLOCKS: 0 pick_splits chooses 3 or 4 blocks per CU, 3 / 4 pins it, -1 the old ceil(3 CUs / tiles)
 
 int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
@@ -429,8 +447,12 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     }
     const long grid = (long)a.tiles_m * a.tiles_n;
     NPM_ARG(grid < (1L << 31));
-    if (tall) hipLaunchKernelGGL(conv_fwd_glds_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
-    else if (dma) hipLaunchKernelGGL(conv_fwd_glds_kernel<false>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    if (tall && g_conv_math == 2) hipLaunchKernelGGL((conv_fwd_glds_kernel<true, 2>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (tall && g_conv_math == 1) hipLaunchKernelGGL((conv_fwd_glds_kernel<true, 1>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (tall) hipLaunchKernelGGL((conv_fwd_glds_kernel<true, 0>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (dma && g_conv_math == 2) hipLaunchKernelGGL((conv_fwd_glds_kernel<false, 2>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (dma && g_conv_math == 1) hipLaunchKernelGGL((conv_fwd_glds_kernel<false, 1>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
+    else if (dma) hipLaunchKernelGGL((conv_fwd_glds_kernel<false, 0>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else if (vec) hipLaunchKernelGGL(conv_fwd_kernel<true>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else hipLaunchKernelGGL(conv_fwd_kernel<false>, dim3((int)grid), dim3(NTHREADS), 0, s, a);
     NPM_CHECK_LAUNCH();
@@ -442,6 +464,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
 extern "C" int npm_conv_set_dma(int on) { g_conv_dma = on; return NPM_OK; }
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu) { g_wgrad_blocks_per_cu = per_cu; return NPM_OK; }
 extern "C" int npm_conv_set_wave_prio(int bits) { g_conv_wave_prio = bits; return NPM_OK; }
+extern "C" int npm_conv_set_math(int mode) { g_conv_math = mode; return NPM_OK; }
 
 extern "C" {
 
@@ -503,7 +526,7 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     // pick_splits keeps every CU equally full.
     if (tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
         if (g_wgrad_blocks_per_cu < 0) splits = (int)std::min<long>((3L * npm::ctx().num_cus + tiles - 1) / tiles, nkt / 8);
-        else splits = pick_splits(tiles, nkt, npm::ctx().num_cus, g_wgrad_blocks_per_cu);
+        else splits = pick_splits(tiles, nkt, npm::ctx().num_cus, g_wgrad_blocks_per_cu, g_conv_math == 2 ? 2 : g_conv_math == 1 ? 3 : 4);
     }
     splits = std::max(1, splits);
     const int kt_per = (nkt + splits - 1) / splits;
@@ -527,7 +550,9 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     const bool dma = g_conv_dma && vec && pixels % GK == 0 && a.k_per_split % GK == 0 &&
                      ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) &&
                      (long)a.k_per_split * c_out * 4 < (1L << 30);
-    if (dma) hipLaunchKernelGGL(conv_wgrad_glds_kernel, dim3(grid), dim3(NTHREADS), 0, s, a);
+    if (dma && g_conv_math == 2) hipLaunchKernelGGL(conv_wgrad_glds_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
+    else if (dma && g_conv_math == 1) hipLaunchKernelGGL(conv_wgrad_glds_kernel<1>, dim3(grid), dim3(NTHREADS), 0, s, a);
+    else if (dma) hipLaunchKernelGGL(conv_wgrad_glds_kernel<0>, dim3(grid), dim3(NTHREADS), 0, s, a);
     else if (vec) hipLaunchKernelGGL(conv_wgrad_kernel<true>, dim3(grid), dim3(NTHREADS), 0, s, a);
     else hipLaunchKernelGGL(conv_wgrad_kernel<false>, dim3(grid), dim3(NTHREADS), 0, s, a);
     NPM_CHECK_LAUNCH();

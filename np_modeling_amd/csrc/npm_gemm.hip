@@ -171,7 +171,14 @@ sgemm_glds_kernel(const GemmArgs p) {
     constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
     constexpr int A_PW = 4 / WN, B_PW = 4 / WM;          // 1 KiB DMA pieces per wave and K tile
     static_assert(A_PW * WM * WN * 16 == TM && B_PW * WM * WN * 16 == TN, "pieces must tile the operands");
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    // MATH 2 runs two blocks per CU (200 registers): three stages, tile kt + 2 in flight while kt is consumed, a
+    // counted vmcnt and a bare s_barrier so that the newest DMA stays in flight (measured +1..2 % in the C5 step;
+    // no gain for the modes that keep three or four blocks per CU).
+#ifndef NPM_MATH_STAGES
+#define NPM_MATH_STAGES 3
+#endif
+    constexpr int NSTAGE = MATH == 2 ? NPM_MATH_STAGES : 2;
+    __shared__ __attribute__((aligned(16))) float smem[NSTAGE * STAGE];
 
     prio_high(p.e.prio & 1);
     const int tid = threadIdx.x;
@@ -241,14 +248,25 @@ sgemm_glds_kernel(const GemmArgs p) {
     long long t_start = 0, t_first = 0, t_loop = 0, r_start = 0;
     if (p.trace) { t_start = __builtin_amdgcn_s_memtime(); r_start = __builtin_amdgcn_s_memrealtime(); }
     if (nkt > 0) issue(0, 0);
+    if (NSTAGE == 3 && nkt > 1) issue(1, 1);
     prio_low(p.e.prio & 1);
+    int stage = 0;
     for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed (every wave's pieces) and everybody is done reading the other stage
-        if (!(p.ablate & 4)) __syncthreads();
-        if (p.trace && kt == 0) t_first = __builtin_amdgcn_s_memtime();
-        if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
-        const float *sA = smem + (kt & 1) * STAGE;
+        // tile kt has landed (every wave's pieces) and everybody is done reading the stage about to be refilled
+        if (NSTAGE == 3) {
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PW + B_PW) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
+        } else {
+            if (!(p.ablate & 4)) __syncthreads();
+            if (p.trace && kt == 0) t_first = __builtin_amdgcn_s_memtime();
+            if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
+        }
+        const float *sA = smem + stage * STAGE;
         const float *sB = sA + A_TILE;
+        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
         if (KSUM && do_ksum) {
             const float *st = (KSUM == 1 ? sB : sA) + (tid & 127);          // both tiles are [16 k][128] here
             for (int r = ks_row0; r < GK; r += 2 * ks_share) ks_acc += st[r * 128];
@@ -387,7 +405,10 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 extern "C" int npm_conv_set_dma(int on);
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
 extern "C" int npm_conv_set_wave_prio(int bits);
+extern "C" int npm_conv_set_math(int mode);
 
+extern "C" int npm_set_math(int mode) { return npm_set_tuning(NPM_TUNE_GEMM_MATH, mode); }
+extern "C" int npm_get_math(void) { return g_math; }
 extern "C" int npm_debug_gemm_trace(long long *buf) { g_trace = buf; return NPM_OK; }
 
 extern "C" int npm_set_tuning(int knob, int value) {
@@ -399,7 +420,10 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         case NPM_TUNE_CONV_WGRAD_BLOCKS: return npm_conv_set_wgrad_blocks(value);
-        case NPM_TUNE_GEMM_MATH: g_math = value; return NPM_OK;
+        case NPM_TUNE_GEMM_MATH:
+            if (value < 0 || value > 2) return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: NPM_TUNE_GEMM_MATH takes 0, 1 or 2");
+            g_math = value;
+            return npm_conv_set_math(value);
         case NPM_TUNE_GEMM_WAVE_PRIO: g_wave_prio = value; return npm_conv_set_wave_prio(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
@@ -482,7 +506,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
-        splits = pick_splits(tiles, nkt, npm::ctx().num_cus);
+        splits = pick_splits(tiles, nkt, npm::ctx().num_cus, 0, g_math == 2 ? 2 : g_math == 1 ? 3 : 4);
     }
     if (!linear_epi) splits = 1;
     if (splits > nkt) splits = nkt > 0 ? nkt : 1;

@@ -569,15 +569,17 @@ __device__ __forceinline__ void mma_tile16_math(const float *__restrict__ sA, co
 }
 
 // Split-K factor for a grid of `tiles` output tiles over `nkt` K tiles.  All blocks of such a launch are
-// resident at once (3-4 fit a CU) and run equally long, so the launch lasts as long as the fullest CU:
-// cost(s) = ceil(tiles * s / CUs) / s.  Candidates leave the fullest CU with 3 or 4 blocks (fewer cannot
-// keep the MFMA pipe busy); ties go to fewer splits.  `force_per_cu` > 0 pins the blocks-per-CU target.
-inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0) {
+// resident at once (`resident` fit a CU: 4 with the f32 MFMA, 3 / 2 with the split-bf16 modes) and run equally
+// long, so the launch lasts as long as the fullest CU: cost(s) = ceil(tiles * s / CUs) / s.  Candidates leave the
+// fullest CU with `resident` or `resident - 1` blocks (fewer cannot keep the matrix pipe busy, more would queue a
+// second generation); ties go to fewer splits.  `force_per_cu` > 0 pins the blocks-per-CU target.
+inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0, int resident = 4) {
     const long max_s = nkt / 8;
     int best = 1;
     double best_cost = 1e30;
-    for (int per_cu = 3; per_cu <= 4; ++per_cu) {
-        if (force_per_cu > 0 && per_cu != force_per_cu && !(force_per_cu > 4 && per_cu == 4)) continue;
+    const int lo = resident > 2 ? resident - 1 : resident;
+    for (int per_cu = lo; per_cu <= resident; ++per_cu) {
+        if (force_per_cu > 0 && force_per_cu <= resident && per_cu != force_per_cu) continue;
         long s = per_cu * cus / tiles;
         if (s > max_s) s = max_s;
         if (s < 1) s = 1;

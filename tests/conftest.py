@@ -39,3 +39,16 @@ def assert_close(got, ref, tol=1e-5, what=''):
     assert got.shape == ref.shape, f'{what}: shape {got.shape} vs {ref.shape}'
     scale = np.abs(ref).max() if ref.size else 0.0
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * scale + 1e-30, err_msg=what)
+
+
+MATH_MODES = ['f32', 'bf16x3', 'bf16x3_fast']
+
+
+@pytest.fixture(params=MATH_MODES)
+def math_mode(request):
+    """Runs the test once per arithmetic of the matrix products (include/npm_hip.h npm_set_math); back to the
+    default afterwards."""
+    import np_modeling_amd
+    np_modeling_amd.set_math(request.param)
+    yield request.param
+    np_modeling_amd.set_math('f32')

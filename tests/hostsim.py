@@ -297,6 +297,13 @@ class HostSim:
         _vec(y, n)[:] = np.where(mk != 0, _vec(x, n) / np.float32(keep), 0)
         return 0
 
+    def npm_set_math(self, mode):
+        self.math = int(mode)
+        return 0
+
+    def npm_get_math(self):
+        return getattr(self, 'math', 0)
+
     def npm_set_tuning(self, knob, value):
         return 0
 

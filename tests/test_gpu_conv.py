@@ -23,7 +23,7 @@ def rand(shape):
 
 @pytest.mark.parametrize('name,shape,channels,k', [('conv_k3', [3, 9, 7, 8], 12, 3), ('conv_k5', [2, 8, 8, 4], 6, 5),
                                                    ('conv_k1', [2, 6, 5, 8], 4, 1)])
-def test_conv_golden(npm, name, shape, channels, k):
+def test_conv_golden(npm, name, shape, channels, k, math_mode):
     """Flow of reference layers/conv_test.py:37-107 at fixture size, seeded like make_golden.py."""
     g = load_golden(name)
     np.random.seed(0)
@@ -46,7 +46,7 @@ def test_conv_golden(npm, name, shape, channels, k):
                                            (3, 6, 6, 20, 132, 1), (1, 3, 40, 8, 8, 7),
                                            (2, 20, 12, 64, 128, 3),       # grad_x takes the tall 256x64 tile (N = 64)
                                            (1, 9, 9, 16, 48, 5), (3, 7, 5, 32, 16, 3)])
-def test_conv_kernels_vs_oracle(npm, n, h, w, c0, c1, k):
+def test_conv_kernels_vs_oracle(npm, n, h, w, c0, c1, k, math_mode):
     from np_modeling_amd import _C, device as D
     lib = _C.lib()
     rng = np.random.default_rng(n * 131 + h * 17 + c0 + k)

@@ -41,7 +41,7 @@ def _params(enc):
 
 
 @pytest.mark.parametrize('name', ['encoder_prenorm', 'encoder_postnorm'])
-def test_encoder_golden(npm, name):
+def test_encoder_golden(npm, name, math_mode):
     """Seeded like oracle/make_golden.py: the lazily drawn parameters must equal the
     reference's bit for bit, then forward / dx / every updated parameter must match."""
     g = load_golden(name)
@@ -60,7 +60,7 @@ def test_encoder_golden(npm, name):
 
 
 @pytest.mark.parametrize('norm_first', [True, False])
-def test_encoder_reference_test_shape(npm, norm_first):
+def test_encoder_reference_test_shape(npm, norm_first, math_mode):
     """B16, S32, F128, H8, U256 (reference layers/transformer_test.py:98-156), weights scaled
     down like a trained model so activations stay O(1)."""
     np.random.seed(0)
@@ -125,7 +125,7 @@ for _n in ('wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo'):
 
 
 @pytest.mark.parametrize('name', ['decoder_prenorm', 'decoder_postnorm'])
-def test_decoder_golden(npm, name):
+def test_decoder_golden(npm, name, math_mode):
     """TransformerDecoder (reference transformer.py:95-203, test transformer_test.py:159-219): seeded
     parameters equal the reference's, then output, (dq, dkv) and all 26 updated parameters match."""
     g = load_golden(name)

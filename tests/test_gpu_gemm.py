@@ -18,6 +18,13 @@ def D():
     return device
 
 
+@pytest.fixture(autouse=True)
+def _every_math_mode(math_mode):
+    """Every test of this module runs under the exact-f32 MFMA and under both split-bf16 modes, at the same
+    tolerances (shapes off the LDS-DMA path fall back to the f32 kernel in every mode)."""
+    return math_mode
+
+
 def _ref(a, b, ta, tb):
     a = a.astype(np.float64)
     b = b.astype(np.float64)
@@ -223,6 +230,43 @@ def test_bias_gradient_beside_weight_gradient(D, m, n, k, which):
     host = sums.numpy()
     assert host[0] == 55.0 and host[-1] == 55.0
     assert_close(host[1:-1], src.astype(np.float64).sum(axis=0), tol=3e-6)
+
+
+def test_split_math_error_statistics(D):
+    """The split-bf16 modes carry fp32-class error: against fp64 at K = 4096 the rms error of 'bf16x3' is not above
+    the exact-f32 MFMA's and its mean error is as small (no bias); 'bf16x3_fast' has the documented negative bias
+    of a fraction of an ulp, far below its rms error."""
+    import np_modeling_amd as npm
+    rng = np.random.default_rng(0)
+    m, n, k = 256, 256, 4096
+    a = rng.standard_normal((m, k), dtype=np.float32)
+    b = (rng.standard_normal((k, n), dtype=np.float32) / 64).astype(np.float32)      # outputs ~ N(0, 1)
+    ref = a.astype(np.float64) @ b.astype(np.float64)
+    da, db = D.from_host(a), D.from_host(b)
+    stats = {}
+    for mode in ('f32', 'bf16x3', 'bf16x3_fast'):
+        npm.set_math(mode)
+        c = D.empty([m, n])
+        D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(c, n))
+        err = c.numpy().astype(np.float64) - ref
+        stats[mode] = (err.mean(), np.sqrt((err ** 2).mean()))
+    ulp = 2.0 ** -23
+    assert stats['f32'][1] < 4 * ulp and abs(stats['f32'][0]) < 0.05 * ulp
+    assert stats['bf16x3'][1] <= 1.05 * stats['f32'][1] and abs(stats['bf16x3'][0]) < 0.05 * ulp
+    assert stats['bf16x3_fast'][1] <= 1.05 * stats['f32'][1] and abs(stats['bf16x3_fast'][0]) < 1.0 * ulp
+
+
+def test_math_mode_api(D):
+    import np_modeling_amd as npm
+    from np_modeling_amd import _C
+    with pytest.raises(ValueError):
+        npm.set_math('tf32')
+    with pytest.raises(_C.NpmError):
+        _C.check(_C.lib().npm_set_math(7), 'npm_set_math')
+    npm.set_math('bf16x3')
+    assert npm.get_math() == 'bf16x3'
+    npm.set_math('f32')
+    assert npm.get_math() == 'f32'
 
 
 def test_bias_gradient_arguments(D):

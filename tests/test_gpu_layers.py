@@ -25,7 +25,7 @@ def rand(shape):
 
 # ---- Dense / Linear ---------------------------------------------------------------------
 @pytest.mark.parametrize('name', ['dense', 'linear'])
-def test_dense_golden(npm, name):
+def test_dense_golden(npm, name, math_mode):
     """Flow of reference layers/mlp_test.py:35-94: aliases of w and b taken before backward
     observe the in-place SGD update."""
     g = load_golden(name)
@@ -209,7 +209,7 @@ _MHA = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
 
 
 @pytest.mark.parametrize('name', ['mha_self', 'mha_cross'])
-def test_mha_golden(npm, name):
+def test_mha_golden(npm, name, math_mode):
     g = load_golden(name)
     layer = npm.layers.MultiHeadAttention(num_heads=int(g['heads']))
     kv = g.get('kv')
@@ -229,7 +229,7 @@ def test_mha_golden(npm, name):
         np.testing.assert_array_equal(np.asarray(getattr(layer, '_' + n)), g[n + '0'])   # deepcopy isolated
 
 
-def test_mha_reference_test_shape_vs_oracle(npm):
+def test_mha_reference_test_shape_vs_oracle(npm, math_mode):
     """B16, Sq32, F128, H8 -- reference layers/attentions_test.py:13-85 (self-attention)."""
     np.random.seed(0)
     layer = npm.layers.MultiHeadAttention(num_heads=8)
