@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 import numpy as np  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2516.6     # same guide: v_mfma_f32_32x32x16_bf16, dense (16x the f32 MFMA rate)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -122,6 +123,10 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16x3_fast'],
+                    help="arithmetic of the matrix products for the headline measurement (include/npm_hip.h npm_set_math)")
+    ap.add_argument('--no-alt-math', action='store_true',
+                    help="skip the second timed region that repeats the K steps with --math bf16x3 ('alt_math' in the JSON)")
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -135,6 +140,7 @@ def main():
     from np_modeling_amd import device as D, parallel
 
     comm = parallel.init('avg')
+    npm.set_math(args.math)
     rng = np.random.default_rng(0)                       # identical parameters on every rank
     params = make_params(rng, args.features, args.heads, args.hidden)
     data_rng = np.random.default_rng(1000 + rank)        # per-rank shard of the global batch
@@ -188,7 +194,9 @@ def main():
         'metric': 'fwd+bwd samples/sec, TransformerEncoder d=1024 seq=512',
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
-        'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic N(0,1) fp32 inputs resident in HBM; random-init '
+        'vs_baseline': None,
+        'dtype': 'f32' if args.math == 'f32' else f'f32 ({args.math}: products as six bf16 MFMAs of three-way split operands, fp32 accumulate)',
+        'math': args.math, 'data': 'synthetic N(0,1) fp32 inputs resident in HBM; random-init '
         'weights (reference initializer scaled by 1/sqrt(fan_in))',
         'config': {'workload': f'TransformerEncoder fwd+bwd+SGD step, d_model={args.features}, heads={args.heads}, '
                                f'seq={args.seq}, hidden_units={args.hidden}, pre-norm, batch {args.batch}/GPU '
@@ -208,7 +216,9 @@ def main():
         achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         traffic, traffic_src = load_pmc_traffic(args)
         result['roofline'] = {
-            'kernel': 'sgemm_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family, LDS-DMA pipeline: NN/NT/TN)',
+            'kernel': ('sgemm_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family, LDS-DMA pipeline: NN/NT/TN)' if args.math == 'f32' else
+                       f'sgemm_glds_kernel ({args.math}: six v_mfma_f32_32x32x16_bf16 per fp32 product; achieved counts fp32-equivalent '
+                       'FLOPs against the f32 MFMA peak, the bf16 pipe executes 6x that)'),
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
             'traffic_source': traffic_src,
@@ -221,6 +231,34 @@ def main():
                                 'GBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in sorted(summary.items()) if not k.startswith('sgemm_') and v['ms'] > 0},
         }
+    if args.math == 'f32' and not args.no_alt_math:
+        # Second timed region, same K steps, same barriers: the matrix products on the bf16 pipe (three-way operand
+        # split, fp32-class error -- DESIGN.md 4.1, tests/test_gpu_gemm.py::test_split_math_error_statistics).
+        npm.set_math('bf16x3')
+        step()
+        D.synchronize()
+        if comm.active:
+            comm.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        D.synchronize()
+        if comm.active:
+            comm.barrier()
+        alt = time.perf_counter() - t0
+        if comm.active:
+            alt = comm.allreduce_scalar(alt, parallel.MAX)
+        npm.set_math('f32')
+        alt_value = total_samples / alt
+        result['alt_math'] = {
+            'math': 'bf16x3', 'value': alt_value, 'unit': 'samples/s', 'ms_per_step': 1e3 * alt / args.steps,
+            'steps': args.steps, 'step_tflops_per_gpu': alt_value / world * fps / 1e12,
+            'step_frac_of_fp32_mfma_peak': alt_value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            'executed_bf16_mfma_frac_of_bf16_peak': 6 * alt_value / world * fps / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            'note': 'same workload and timing protocol with npm_set_math(NPM_MATH_BF16X3): fp32 inputs/outputs/accumulators, '
+                    'each product formed from three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16); '
+                    'rms error vs fp64 at or below the exact-f32 MFMA path (profiles/r01_math_error.log). '
+                    'Not the headline: value above is the exact-f32 MFMA path.'}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args, params)
     if rank == 0:
