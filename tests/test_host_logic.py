@@ -190,6 +190,21 @@ def test_grad_scope_bucket_and_deferred_updates(npm):
     assert events == [('update', '_a')]
 
 
+def test_math_mode_api_on_simulator(npm):
+    """set_math / get_math map the names of include/npm_hip.h NPM_MATH_* and reject anything else."""
+    assert npm.get_math() == 'f32'
+    for name in ('bf16x3', 'bf16x3_fast', 'f32'):
+        npm.set_math(name)
+        assert npm.get_math() == name
+    with pytest.raises(ValueError):
+        npm.set_math('bf16')
+    text = open(os.path.join(ROOT, 'include', 'npm_hip.h')).read()
+    import re
+    from np_modeling_amd import _C
+    enum = dict(re.findall(r'NPM_MATH_(\w+) = (\d+)', text))
+    assert {k.lower(): int(v) for k, v in enum.items()} == _C.MATH_MODES
+
+
 def test_shard_helper(npm):
     from np_modeling_amd import parallel
 
