@@ -465,10 +465,14 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
         db[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     }
     const float inv_d = 1.0f / (float)d;
+    // The residual row is requested together with dz and x, before anything waits (it used to be loaded after the
+    // two reductions: 0.459 -> 0.429 ms at 131072 x 1024).  Prefetching the next row's dz / x under the reductions
+    // doubled the registers and changed nothing (0.334 -> 0.330 ms): this kernel is not latency-bound.
     for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
-        float4 g[VPL], yh[VPL];
+        float4 g[VPL], yh[VPL], res[VPL];
         load_row<VPL>(dz + row * d, nvec, lane, g, 0.f);
         load_row<VPL>(x + row * d, nvec, lane, yh, 0.f);
+        if (residual) load_row<VPL>(residual + row * d, nvec, lane, res, 0.f);
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -491,10 +495,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
             o.x = rs * (g[j].x - m1 - yh[j].x * m2); o.y = rs * (g[j].y - m1 - yh[j].y * m2);
             o.z = rs * (g[j].z - m1 - yh[j].z * m2); o.w = rs * (g[j].w - m1 - yh[j].w * m2);
             if (c < nvec) {
-                if (residual) {
-                    const float4 r = reinterpret_cast<const float4 *>(residual + row * d)[c];
-                    o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
-                }
+                if (residual) { o.x += res[j].x; o.y += res[j].y; o.z += res[j].z; o.w += res[j].w; }
                 reinterpret_cast<float4 *>(dx + row * d)[c] = o;
             }
         }

@@ -112,7 +112,12 @@ def test_encoder_fused_equals_unfused(npm, norm_first):
         dx2 = np.asarray(enc._backward_unfused(npm.as_device(dy), r2, scope))
     assert_close(dx1, dx2, tol=5e-6)
     assert r1.grads.keys() == r2.grads.keys() and len(r1.grads) == 16
+    bq_scale = max(np.abs(v).max() for k, v in r1.grads.items() if k[1] == '_bq')
     for key in r1.grads:
+        if key[1] == '_bk':
+            # zero in real arithmetic (every row of datt sums to 0): what either composition stores is rounding noise
+            assert np.abs(r1.grads[key]).max() < 1e-4 * bq_scale and np.abs(r2.grads[key]).max() < 1e-4 * bq_scale
+            continue
         assert_close(r1.grads[key], r2.grads[key], tol=5e-6, what=str(key))
 
 

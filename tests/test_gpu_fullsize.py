@@ -141,7 +141,11 @@ def test_encoder_full_size_fused_equals_unfused(npm):
     g1 = {k: np.asarray(v) for k, v in r1.grads.items()}
     g2 = {k: np.asarray(v) for k, v in r2.grads.items()}
     assert len(g1) == 16 and g1.keys() == g2.keys()
+    bq_scale = max(np.abs(v).max() for k, v in g1.items() if k[1] == '_bq')
     for k in g1:
+        if k[1] == '_bk':      # rounding noise around an exact zero in both compositions (see the additivity test)
+            assert np.abs(g1[k]).max() < 1e-4 * bq_scale and np.abs(g2[k]).max() < 1e-4 * bq_scale
+            continue
         assert_close(g1[k], g2[k], tol=1e-5, what=str(k[:2]))
 
 
