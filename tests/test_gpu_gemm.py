@@ -211,6 +211,7 @@ def test_colsum_in_epilogue(D, m, n, k, batch):
 
 @pytest.mark.parametrize('m,n,k', [(128, 128, 64), (256, 384, 4096),      # LDS-DMA path, one split and split-K
                                    (1024, 256, 32768),                     # many splits: 8 tile rows x 2 tile columns
+                                   (4096, 256, 2048), (256, 4096, 2048),   # more than 16 blocks share an operand tile
                                    (200, 72, 1040), (130, 20, 33), (5, 3, 7), (64, 640, 16), (384, 16, 2048)])
 @pytest.mark.parametrize('which', ['bsum', 'asum'])
 def test_bias_gradient_beside_weight_gradient(D, m, n, k, which):
