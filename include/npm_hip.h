@@ -135,7 +135,9 @@ int npm_set_tuning(int knob, int value);
  *                         bits, the parts add up to the fp32 value) and the product is formed as the six largest
  *                         cross terms on v_mfma_f32_32x32x16_bf16, the five small terms in accumulators of their own.
  *                         Error against fp64 is at or below the f32 mode's (tools/math_bias.py);
- *                         results are NOT bit-equal to the f32 mode.
+ *                         results are NOT bit-equal to the f32 mode.  Non-finite operands: an infinity (or a
+ *                         value that rounds to one in bf16, |a| > 3.389e38) splits into inf + (inf - inf) and gives
+ *                         NaN where the f32 mode gives inf; operands below 2^-110 lose their low parts to underflow.
  *   NPM_MATH_BF16X3_FAST  the same six terms into one accumulator: fewer registers, faster; the matrix pipe cuts
  *                         small addends against a large accumulator, which leaves a bias of about -0.5 ulp per
  *                         4096 accumulated terms (visible in column checksums, not per element). */
