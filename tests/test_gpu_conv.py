@@ -75,6 +75,38 @@ def test_conv_kernels_vs_oracle(npm, n, h, w, c0, c1, k, math_mode):
     assert_close(gw, O.conv2d_grad_w(dy.astype(np.float64), x.astype(np.float64), k), tol=5e-6)
 
 
+def test_conv_random_sweep(npm, math_mode):
+    """Randomised Conv2D geometries (odd kernels 1..7, channel counts on and off the DMA path's multiples of 16 / 4,
+    images smaller than the kernel's reach) through forward, input gradient and filter gradient."""
+    from np_modeling_amd import _C, device as D
+    lib = _C.lib()
+    rng = np.random.default_rng(77)
+    for case in range(24):
+        n, h, w = int(rng.integers(1, 5)), int(rng.integers(1, 20)), int(rng.integers(1, 20))
+        c0 = int(rng.choice([1, 3, 4, 8, 16, 20, 32, 48, 64]))
+        c1 = int(rng.choice([1, 2, 4, 12, 16, 32, 64, 80, 128, 144]))
+        k = int(rng.choice([1, 3, 3, 5, 7]))
+        x = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+        filt = rng.standard_normal((k, k, c0, c1)).astype(np.float32)
+        bias = rng.standard_normal(c1).astype(np.float32)
+        dy = rng.standard_normal((n, h, w, c1)).astype(np.float32)
+        dx_, df, db, ddy = D.from_host(x), D.from_host(filt), D.from_host(bias), D.from_host(dy)
+        y, pre = D.empty([n, h, w, c1]), D.empty([n, h, w, c1])
+        desc = _C.npm_conv2d(n=n, h=h, w=w, c_in=c0, c_out=c1, ksize=k, x=dx_.ptr, filt=df.ptr, bias=db.ptr,
+                             y=y.ptr, pre=pre.ptr, relu=1)
+        _C.check(lib.npm_conv2d_fwd(C.byref(desc)))
+        what = f'case {case}: n={n} h={h} w={w} c0={c0} c1={c1} k={k} math={math_mode}'
+        x64, f64, dy64 = x.astype(np.float64), filt.astype(np.float64), dy.astype(np.float64)
+        _, want_pre = O.conv_layer_fwd(x64, f64, bias.astype(np.float64))
+        assert_close(pre, want_pre, tol=3e-6, what=what + ' fwd')
+        np.testing.assert_array_equal(y.numpy(), np.maximum(pre.numpy(), 0))
+        gx, gw = D.empty([n, h, w, c0]), D.empty([k, k, c0, c1])
+        _C.check(lib.npm_conv2d_bwd_x(ddy.ptr, df.ptr, gx.ptr, n, h, w, c0, c1, k))
+        _C.check(lib.npm_conv2d_bwd_w(ddy.ptr, dx_.ptr, gw.ptr, n, h, w, c0, c1, k))
+        assert_close(gx, O.conv2d_grad_x(dy64, f64), tol=3e-6, what=what + ' grad_x')
+        assert_close(gw, O.conv2d_grad_w(dy64, x64, k), tol=5e-6, what=what + ' grad_w')
+
+
 def test_conv_rejects_even_kernel(npm):
     layer = npm.layers.Conv2D(channels=4, kernel_size=2)
     with pytest.raises(AssertionError):

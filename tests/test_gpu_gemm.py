@@ -257,6 +257,83 @@ def test_split_math_error_statistics(D):
     assert stats['bf16x3_fast'][1] <= 1.05 * stats['f32'][1] and abs(stats['bf16x3_fast'][0]) < 1.0 * ulp
 
 
+@pytest.mark.parametrize('seed', range(6))
+def test_random_sweep(D, seed):
+    """Randomised descriptors against NumPy fp64: layouts, sizes on and off the tile / DMA boundaries, padded and
+    unaligned row pitches, two batch dimensions with head-style strides ([b0, rows, b1, cols] storage), every
+    epilogue the ABI accepts, split-K requests, the operand column sums; guard words around C and the padding
+    columns inside it check that nothing else is written."""
+    rng = np.random.default_rng(1000 + seed)
+    sizes = [1, 2, 3, 5, 16, 17, 31, 32, 33, 48, 64, 65, 100, 127, 128, 129, 160, 200, 256, 272, 384]
+    guard = 5
+    for case in range(40):
+        ta, tb = [(False, False), (False, True), (True, False)][rng.integers(3)]
+        m, n = int(rng.choice(sizes)), int(rng.choice(sizes))
+        k = int(rng.choice(sizes + [512, 1024, 2048 + 16]))
+        b0, b1 = (1, 1) if rng.random() < 0.6 else (int(rng.integers(1, 4)), int(rng.integers(1, 4)))
+        a_rows, a_cols = (k, m) if ta else (m, k)
+        b_rows, b_cols = (n, k) if tb else (k, n)
+
+        def stored(rows, cols):                       # [b0, rows, b1, cols + pad] -> (array, ld, stride0, stride1)
+            cp = cols + int(rng.choice([0, 0, 4, 8, 1, 3]))
+            arr = rng.standard_normal((b0, rows, b1, cp)).astype(np.float32)
+            return arr, b1 * cp, rows * b1 * cp, cp
+
+        a, lda, sa0, sa1 = stored(a_rows, a_cols)
+        b, ldb, sb0, sb1 = stored(b_rows, b_cols)
+        c_init, ldc, sc0, sc1 = stored(m, n)
+        c_init[:] = -777.0
+        res = aux = None
+        mode = int(rng.integers(7))        # 0 plain 1 bias 2 bias+res 3 bias+relu_save 4 res 5 relu_mask 6 res+relu_mask
+        alpha = float(rng.choice([1.0, 1.0, 0.5, -2.0]))
+        kwargs = dict(trans_a=ta, trans_b=tb, batch=(b0, b1), alpha=alpha)
+        bias = None
+        if mode in (1, 2, 3):
+            bias = rng.standard_normal(n).astype(np.float32)
+            kwargs['bias'] = D.from_host(bias)
+        if mode in (2, 4, 6):
+            res = rng.standard_normal(c_init.shape).astype(np.float32)
+            dres = D.from_host(res)
+            kwargs['residual'] = D.Mat(dres, ldc)
+        if mode in (3, 5, 6):
+            aux = rng.standard_normal(c_init.shape).astype(np.float32)
+            daux = D.from_host(aux)
+            kwargs['relu_save' if mode == 3 else 'relu_mask'] = D.Mat(daux, ldc)
+        if mode in (0, 1, 2, 4) and rng.random() < 0.3:
+            kwargs['split_k'] = int(rng.choice([1, 2, 5]))
+        sums = which = None
+        if (b0, b1) == (1, 1) and ta and not tb and mode in (0, 1, 2, 4) and rng.random() < 0.6:
+            which = 'asum_out' if rng.random() < 0.5 else 'bsum_out'
+            sums = D.full([m if which == 'asum_out' else n], np.nan)
+            kwargs[which] = sums
+        flat = np.concatenate([np.full(guard, -777.0, np.float32), c_init.ravel(), np.full(guard, -777.0, np.float32)])
+        da, db, dc = D.from_host(a), D.from_host(b), D.from_host(flat)
+        D.gemm(m, n, k, D.Mat(da, lda, sa0, sa1), D.Mat(db, ldb, sb0, sb1),
+               D.Mat(dc.flat_view(guard, [c_init.size]), ldc, sc0, sc1), **kwargs)
+        what = (f'seed {seed} case {case}: ta={ta} tb={tb} m={m} n={n} k={k} batch={(b0, b1)} ld={(lda, ldb, ldc)} '
+                f'mode={mode} alpha={alpha} {sorted(kwargs)}')
+        got = dc.numpy()
+        assert np.all(got[:guard] == -777.0) and np.all(got[-guard:] == -777.0), what
+        body = got[guard:-guard].reshape(c_init.shape)
+        assert np.all(body[..., n:] == -777.0), what                     # padding columns of every head
+        a64, b64 = a[..., :a_cols].astype(np.float64), b[..., :b_cols].astype(np.float64)
+        eq = ('zkhm' if ta else 'zmhk') + ',' + ('znhk' if tb else 'zkhn') + '->zmhn'
+        ref = alpha * np.einsum(eq, a64, b64)
+        if bias is not None:
+            ref = ref + bias
+        if res is not None:
+            ref = ref + res[..., :n]
+        if mode == 3:
+            assert_close(daux.numpy()[..., :n], ref, tol=3e-6, what=what + ' (saved pre-activation)')
+            ref = np.maximum(ref, 0.0)
+        if mode in (5, 6):
+            ref = np.where(aux[..., :n] >= 0, ref, 0.0)
+        assert_close(body[..., :n], ref, tol=3e-6, what=what)
+        if sums is not None:
+            src = a64 if which == 'asum_out' else b64
+            assert_close(sums, src.reshape(k, -1).sum(axis=0), tol=3e-6, what=what + ' (operand sums)')
+
+
 def test_math_mode_api(D):
     import np_modeling_amd as npm
     from np_modeling_amd import _C
