@@ -14,6 +14,7 @@ tools/clock_sampler.sh "$OUT/clocks_bf16x3.log" -- timeout -k 10 200 python benc
     echo "math $m: $(python3 -c "import json;d=json.load(open('$f'));print(round(d['value'],1),'samples/s',round(d['ms_per_step'],2),'ms/step')")  $(python3 tools/clock_summary.py $OUT/clocks_$m.log)"; done; } > "$OUT/r01_clock_power.log"
 echo "== config bench"; { for m in f32 bf16x3 bf16x3_fast; do echo "NPM_MATH=$m"; NPM_MATH=$m timeout -k 10 300 python tools/config_bench.py --kernels; done; } > "$OUT/r01_config_bench.log" 2>&1
 echo "== gemm shapes"; { for t in 10=0 10=2 10=1; do timeout -k 10 200 python tools/gemm_bench.py --tune $t; done; } > "$OUT/r01_gemm_shapes.log" 2>&1
+echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/r01_rowops.log" 2>&1
 echo "== math error"; timeout -k 10 100 python tools/math_bias.py > "$OUT/r01_math_error.log" 2>&1
 echo "== rocprofv3 kernel trace"
 cd /tmp && export TMPDIR=/tmp
