@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <unistd.h>
 
 #include "npm_comm.h"
 
@@ -22,6 +23,21 @@ int fail(int code, const char *fmt, ...) {
     va_end(ap);
     return code ? code : -1;
 }
+
+// RCCL prints a version banner on STDOUT when it initialises.  The host program's stdout is a data channel
+// (bench.py prints exactly one JSON line), so stdout points at stderr while RCCL initialises.
+struct StdoutToStderr {
+    int saved;
+    StdoutToStderr() {
+        fflush(stdout);
+        saved = dup(STDOUT_FILENO);
+        if (saved >= 0) dup2(STDERR_FILENO, STDOUT_FILENO);
+    }
+    ~StdoutToStderr() {
+        fflush(stdout);
+        if (saved >= 0) { dup2(saved, STDOUT_FILENO); close(saved); }
+    }
+};
 
 struct Comm {
     bool ready = false;
@@ -69,7 +85,10 @@ int npm_comm_unique_id(char *id) {
     if (!id) return fail(-1, "npm_comm_unique_id: null id");
     static_assert(sizeof(ncclUniqueId) == NPM_COMM_ID_BYTES, "id size");
     ncclUniqueId uid;
-    NCCLC(ncclGetUniqueId(&uid));
+    {
+        StdoutToStderr quiet;
+        NCCLC(ncclGetUniqueId(&uid));
+    }
     memcpy(id, &uid, sizeof(uid));
     return 0;
 }
@@ -79,7 +98,10 @@ int npm_comm_init(const char *id, int rank, int nranks, void *compute_stream) {
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(-1, "npm_comm_init: bad arguments");
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof(uid));
-    NCCLC(ncclCommInitRank(&g.comm, nranks, uid, rank));
+    {
+        StdoutToStderr quiet;
+        NCCLC(ncclCommInitRank(&g.comm, nranks, uid, rank));
+    }
     g.rank = rank;
     g.nranks = nranks;
     g.compute = (hipStream_t)compute_stream;

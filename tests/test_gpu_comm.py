@@ -68,3 +68,21 @@ def test_sync_parameters_walks_composites(comm):
     for a, p in zip(before, params):
         np.testing.assert_array_equal(a, np.asarray(p))
     parallel.set_communicator(None)
+
+
+def test_rccl_init_keeps_stdout_clean():
+    """RCCL prints a version banner on stdout when it initialises; a program whose stdout is data (bench.py's single
+    JSON line) must not see it: the shim points stdout at stderr while RCCL initialises."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from np_modeling_amd import _C, parallel\n"
+            "_C.lib()\n"
+            "c = parallel.RcclCommunicator(0, 1, parallel.RcclCommunicator.new_unique_id())\n"
+            "c.barrier(); c.close()\n"
+            "print('only-this-line')\n" % root)
+    out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines() == ['only-this-line'], out.stdout
