@@ -1,88 +1,105 @@
-"""Layer protocol -- same call semantics as reference layers/layer.py:11-69.
+"""The call protocol every device layer speaks (what reference layers/layer.py:11-69 defines).
 
-``layer(*inputs)`` runs ``forward``; ``layer(dy, backprop=True, learning_rate=lr)`` or
-``layer(dy, backprop=True, optimizer_=opt)`` runs ``backward`` with the optimizer passed
-positionally last.  The first call of either kind triggers ``initialize(*args)``.
-Parameters are drawn on the HOST with NumPy's global RNG in the reference's order, so a
-seeded run builds bit-identical parameters, then live in HBM as ``DeviceArray``.
+One entry point, three behaviours:
+
+* ``layer(x, ...)``                                   -> ``forward``
+* ``layer(dy, backprop=True, learning_rate=lr)``      -> ``backward`` with a throw-away SGD optimizer
+* ``layer(dy, backprop=True, optimizer_=opt)``        -> ``backward`` with that optimizer (``None`` is allowed)
+
+``backward`` always receives the optimizer as its LAST positional argument.  Whatever the first call is, it first
+runs ``initialize`` with the very same arguments (lazy shapes).  Parameters are drawn on the HOST from NumPy's global
+RNG in the reference's order -- a seeded run builds bit-identical parameters -- and then live in HBM.
 """
 
 from __future__ import annotations
 
 import abc
-from typing import Optional, Sequence
+from typing import Any, Optional, Sequence
 
 import numpy as np
 
 from np_modeling_amd import device as D
-from np_modeling_amd import optimizer
+from np_modeling_amd import optimizer as optimizers
+
+_BOTH_GIVEN = 'Optimizer and learning rate cannot both be specified!'
 
 
-class Layer(metaclass=abc.ABCMeta):
-    def __init__(self, name: str = '', *args, **kwargs):
-        self._name = name
+def _pick_optimizer(learning_rate: Optional[float], optimizer_: Any):
+    """The optimizer a backward call runs with (reference layer.py:38-44)."""
+    if learning_rate is None:
+        return optimizer_
+    if optimizer_ is not None:
+        raise ValueError(_BOTH_GIVEN)
+    return optimizers.SGDOptimizer(learning_rate)
+
+
+class Layer(abc.ABC):
+    """Base of all layers; concrete layers provide ``forward`` and ``backward`` (and usually ``initialize``)."""
+
+    def __init__(self, name: str = '', *_ignored, **_ignored_kw):
         self._initialized = False
-
-    def initialize(self, *args, **kwargs) -> None:
-        pass
-
-    @abc.abstractmethod
-    def forward(self, *args, **kwargs):
-        pass
-
-    @abc.abstractmethod
-    def backward(self, *args, optimizer_, **kwargs):
-        pass
-
-    def __call__(self, *args, backprop: bool = False, learning_rate: Optional[float] = None,
-                 optimizer_: Optional['optimizer.Optimizer'] = None, **kwargs):
-        # reference layer.py:33-45 -- lazy initialisation fires on the first call of any kind
-        if not self._initialized:
-            self.initialize(*args, **kwargs)
-            self._initialized = True
-        if not backprop:
-            return self.forward(*args, **kwargs)
-        if learning_rate is not None and optimizer_ is not None:
-            raise ValueError('Optimizer and learning rate cannot both be specified!')
-        if learning_rate is not None:
-            optimizer_ = optimizer.SGDOptimizer(learning_rate)
-        return self.backward(*args, optimizer_, **kwargs)
+        self._name = name
 
     @property
-    def name(self):
+    def name(self) -> str:
         return self._name
 
-    # -- helpers shared by the device layers ------------------------------------------
+    # ---- what a concrete layer implements ---------------------------------------------------------
+    def initialize(self, *inputs, **kwargs) -> None:
+        """Create parameters from the first call's arguments.  Stateless layers keep this no-op."""
+
+    @abc.abstractmethod
+    def forward(self, *inputs, **kwargs):
+        raise NotImplementedError
+
+    @abc.abstractmethod
+    def backward(self, *grads, optimizer_, **kwargs):
+        raise NotImplementedError
+
+    # ---- dispatch -----------------------------------------------------------------------------------------
+    def __call__(self, *inputs, backprop: bool = False, learning_rate: Optional[float] = None,
+                 optimizer_: Optional['optimizers.Optimizer'] = None, **kwargs):
+        if not self._initialized:                       # first call of ANY kind (a backward call included)
+            self.initialize(*inputs, **kwargs)
+            self._initialized = True
+        if backprop:
+            return self.backward(*inputs, _pick_optimizer(learning_rate, optimizer_), **kwargs)
+        return self.forward(*inputs, **kwargs)
+
+    # ---- shared by the device layers --------------------------------------------------------------------
     def _param(self, attribute: str) -> D.DeviceArray:
-        """Current value of a parameter as a DeviceArray.  Tests and weight binders assign
-        arbitrary array-likes into the private attributes (reference layers/utils.py:52-88);
-        those are moved to the device on first use and the attribute is rebound."""
+        """Current value of a parameter as a DeviceArray.  Tests and weight binders assign arbitrary array-likes
+        into the private attributes (reference layers/utils.py:52-88); such a value moves to the device on first
+        use and the attribute is rebound to the device copy."""
         value = getattr(self, attribute)
-        if not isinstance(value, D.DeviceArray):
-            value = D.as_device(value)
-            setattr(self, attribute, value)
-        return value
+        if isinstance(value, D.DeviceArray):
+            return value
+        on_device = D.as_device(value)
+        setattr(self, attribute, on_device)
+        return on_device
 
 
-class Initializer(metaclass=abc.ABCMeta):
+class Initializer(abc.ABC):
+    """Maps a shape to a host array of initial values."""
+
     def __call__(self, shape: Sequence[int]) -> np.ndarray:
-        pass
+        return None
 
 
 class RandomInitializer(Initializer):
-    """N(0, 1) clipped to [-1, 1] in fp32 from the global NumPy RNG (reference layer.py:57-60)."""
+    """Standard normal draws from the GLOBAL NumPy generator, fp32, clipped to [-1, 1] (reference layer.py:57-60)."""
 
     def __call__(self, shape: Sequence[int]) -> np.ndarray:
-        sample = np.random.normal(size=shape).astype(np.float32)
-        return np.clip(sample, -1.0, 1.0)
+        return np.clip(np.random.normal(size=shape).astype(np.float32), -1.0, 1.0)
 
 
 class StatefulLayer(Layer):
-    """``initializer`` is the FIRST positional argument, as in reference layer.py:64-69."""
+    """A layer with parameters.  NB the constructor takes ``initializer`` as its FIRST positional argument and the
+    name after it, as reference layer.py:64-69 does."""
 
     def __init__(self, initializer: Optional[Initializer] = None, *args, **kwargs):
-        super().__init__(*args, **kwargs)
-        self._initializer = initializer or RandomInitializer()
+        Layer.__init__(self, *args, **kwargs)
+        self._initializer = initializer if initializer is not None else RandomInitializer()
 
     def _new_param(self, shape: Sequence[int]) -> D.DeviceArray:
         return D.as_device(self._initializer(list(shape)))

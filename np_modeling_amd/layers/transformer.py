@@ -21,6 +21,29 @@ def _identity_dropout(*dropouts) -> bool:
     return all(d._drop_prob == 0.0 for d in dropouts)
 
 
+# A transformer layer is a chain of residual blocks around a body (attention or the feed-forward pair):
+#     pre-norm :  y = x + body(norm(drop(x)))          post-norm:  y = norm(drop(x + body(x)))
+# The two helpers below are that block and its mirror image, built from standalone device adds -- the literal
+# (unfused) composition, used when dropout is active, by the decoder, and as the reference the fused encoder is
+# tested against.
+def _block_forward(x, norm, dropout, norm_first: bool, body):
+    x = D.as_device(x)
+    if norm_first:
+        return D.add(D.as_device(body(norm(dropout(x)))), x)
+    return D.as_device(norm(dropout(D.add(D.as_device(body(x)), x))))
+
+
+def _block_backward(dy, norm, dropout, norm_first: bool, body_backward, optimizer_, scope):
+    """``body_backward(dy)`` returns the gradient w.r.t. the body's (first) input; the skip path adds ``dy``."""
+    if not norm_first:
+        dy = dropout.backward(norm._backward_impl(D.as_device(dy), optimizer_, scope))
+    through_skip = D.as_device(dy)
+    through_body = D.as_device(body_backward(through_skip))
+    if norm_first:
+        through_body = D.as_device(dropout.backward(norm._backward_impl(through_body, optimizer_, scope)))
+    return D.add(through_body, through_skip)
+
+
 class TransformerEncoder(layer.Layer):
     def __init__(self, num_heads: int, hidden_units: int, norm_first: bool, drop_rate: float = 0.0,
                  *args, **kwargs):
@@ -77,24 +100,21 @@ class TransformerEncoder(layer.Layer):
             out = self._norm2(out)
         return out.reshape(batch, seq_len_q, features)
 
+    def _feed_forward(self, x):
+        return self._dense2(self._dense1(x))
+
+    def _feed_forward_backward(self, dy, optimizer_, scope):
+        dy = self._dense2._backward_impl(D.as_device(dy), optimizer_, scope)
+        dy = self._dense1._activation.backward(dy)
+        return self._dense1._linear._backward_impl(D.as_device(dy), optimizer_, scope)
+
     def _forward_unfused(self, qkv):
-        """Literal transcription of the reference order with standalone adds (dropout > 0)."""
+        """The reference's composition (transformer.py:29-59) out of standalone kernels: two residual blocks."""
         batch, seq_len_q, features = qkv.shape
-        skip = qkv
-        if self._norm_first:
-            qkv = self._norm1(self._dropout1(qkv))
-        out = D.add(D.as_device(self._self_attention(qkv)), D.as_device(skip))
-        if not self._norm_first:
-            out = self._norm1(self._dropout1(out))
-        out = D.as_device(out).reshape(-1, features)
-        skip = out
-        if self._norm_first:
-            out = self._norm2(self._dropout2(out))
-        out = self._dense2(self._dense1(out))
-        out = D.add(out, skip)
-        if not self._norm_first:
-            out = self._norm2(self._dropout2(out))
-        return D.as_device(out).reshape(batch, seq_len_q, features)
+        out = _block_forward(qkv, self._norm1, self._dropout1, self._norm_first, self._self_attention)
+        out = _block_forward(out.reshape(-1, features), self._norm2, self._dropout2, self._norm_first,
+                             self._feed_forward)
+        return out.reshape(batch, seq_len_q, features)
 
     def backward(self, dy, optimizer_):
         dy = D.as_device(dy)
@@ -133,25 +153,13 @@ class TransformerEncoder(layer.Layer):
         return dy
 
     def _backward_unfused(self, dy, optimizer_, scope):
+        """Mirror of ``_forward_unfused`` (transformer.py:61-92); the attention block sums dquery + dkey + dvalue."""
         batch, seq_len_q, features = dy.shape
-        dy = dy.reshape(-1, features)
-        if not self._norm_first:
-            dy = self._dropout2.backward(self._norm2._backward_impl(dy, optimizer_, scope))
-        dskip = D.as_device(dy)
-        dy = self._dense2._backward_impl(dskip, optimizer_, scope)
-        dy = self._dense1._activation.backward(dy)
-        dy = self._dense1._linear._backward_impl(D.as_device(dy), optimizer_, scope)
-        if self._norm_first:
-            dy = self._dropout2.backward(self._norm2._backward_impl(dy, optimizer_, scope))
-        dy = D.add(D.as_device(dy), dskip).reshape(batch, seq_len_q, features)
-        if not self._norm_first:
-            dy = self._dropout1.backward(self._norm1._backward_impl(dy, optimizer_, scope))
-        dskip = D.as_device(dy)
-        dq, dk, dv = self._self_attention._backward_impl(dskip, optimizer_, scope)
-        dy = D.add3(dq, dk, dv)
-        if self._norm_first:
-            dy = self._dropout1.backward(self._norm1._backward_impl(dy, optimizer_, scope))
-        return D.add(D.as_device(dy), dskip)
+        dy = _block_backward(dy.reshape(-1, features), self._norm2, self._dropout2, self._norm_first,
+                             lambda g: self._feed_forward_backward(g, optimizer_, scope), optimizer_, scope)
+        return _block_backward(dy.reshape(batch, seq_len_q, features), self._norm1, self._dropout1, self._norm_first,
+                               lambda g: D.add3(*self._self_attention._backward_impl(g, optimizer_, scope)),
+                               optimizer_, scope)
 
 
 class TransformerDecoder(layer.Layer):
@@ -177,62 +185,44 @@ class TransformerDecoder(layer.Layer):
         features = q.shape[-1]
         self._dense2 = mlp.Linear(units=features)  # no activation
 
+    def _feed_forward(self, x):
+        return self._dense2(self._dense1(x))
+
     def forward(self, q, kv):
+        """Three residual blocks: self-attention, cross-attention over ``kv``, feed-forward (transformer.py:120-157)."""
         q, kv = D.as_device(q), D.as_device(kv)
         batch, seq_len_q, features = q.shape
-        skip = q
-        if self._norm_first:
-            q = self._norm1(self._dropout1(q))
-        out = D.add(D.as_device(self._self_attention(q)), D.as_device(skip))
-        if not self._norm_first:
-            out = self._norm1(self._dropout1(out))
-        skip = out
-        if self._norm_first:
-            out = self._norm2(self._dropout2(out))
-        out = D.add(D.as_device(self._cross_attention(out, kv)), D.as_device(skip))
-        if not self._norm_first:
-            out = self._norm2(self._dropout2(out))
-        out = D.as_device(out).reshape(-1, features)
-        skip = out
-        if self._norm_first:
-            out = self._norm3(self._dropout3(out))
-        out = self._dense2(self._dense1(out))
-        out = D.add(out, skip)
-        if not self._norm_first:
-            out = self._norm3(self._dropout3(out))
-        return D.as_device(out).reshape(batch, seq_len_q, features)
+        out = _block_forward(q, self._norm1, self._dropout1, self._norm_first, self._self_attention)
+        out = _block_forward(out, self._norm2, self._dropout2, self._norm_first,
+                             lambda x: self._cross_attention(x, kv))
+        out = _block_forward(out.reshape(-1, features), self._norm3, self._dropout3, self._norm_first,
+                             self._feed_forward)
+        return out.reshape(batch, seq_len_q, features)
 
     def backward(self, dy, optimizer_):
+        """Returns ``(dq, dkv)``; ``dkv`` is the cross-attention's dkey + dvalue (transformer.py:159-203)."""
         dy = D.as_device(dy)
         batch, seq_len_q, features = dy.shape
+        kv_grad = []
+
+        def feed_forward_backward(g):
+            g = self._dense2._backward_impl(D.as_device(g), optimizer_, scope)
+            g = self._dense1._activation.backward(g)
+            return self._dense1._linear._backward_impl(D.as_device(g), optimizer_, scope)
+
+        def cross_attention_backward(g):
+            dquery, dkey, dvalue = self._cross_attention._backward_impl(g, optimizer_, scope)
+            kv_grad.append(D.add(dkey, dvalue))
+            return dquery
+
+        def self_attention_backward(g):
+            return D.add3(*self._self_attention._backward_impl(g, optimizer_, scope))
+
         with parallel.grad_scope(0) as scope:
-            dy = dy.reshape(-1, features)
-            if not self._norm_first:
-                dy = self._dropout3.backward(self._norm3._backward_impl(dy, optimizer_, scope))
-            dskip = D.as_device(dy)
-            dy = self._dense2._backward_impl(dskip, optimizer_, scope)
-            dy = self._dense1._activation.backward(dy)
-            dy = self._dense1._linear._backward_impl(D.as_device(dy), optimizer_, scope)
-            if self._norm_first:
-                dy = self._dropout3.backward(self._norm3._backward_impl(dy, optimizer_, scope))
-            dy = D.add(D.as_device(dy), dskip).reshape(batch, seq_len_q, features)
-
-            if not self._norm_first:
-                dy = self._dropout2.backward(self._norm2._backward_impl(dy, optimizer_, scope))
-            dskip = D.as_device(dy)
-            dq, dk, dv = self._cross_attention._backward_impl(dskip, optimizer_, scope)
-            dkv = D.add(dk, dv)
-            dy = dq
-            if self._norm_first:
-                dy = self._dropout2.backward(self._norm2._backward_impl(dy, optimizer_, scope))
-            dy = D.add(D.as_device(dy), dskip)
-
-            if not self._norm_first:
-                dy = self._dropout1.backward(self._norm1._backward_impl(dy, optimizer_, scope))
-            dskip = D.as_device(dy)
-            dq, dk, dv = self._self_attention._backward_impl(dskip, optimizer_, scope)
-            dy = D.add3(dq, dk, dv)
-            if self._norm_first:
-                dy = self._dropout1.backward(self._norm1._backward_impl(dy, optimizer_, scope))
-            dy = D.add(D.as_device(dy), dskip)
-        return dy, dkv
+            dy = _block_backward(dy.reshape(-1, features), self._norm3, self._dropout3, self._norm_first,
+                                 feed_forward_backward, optimizer_, scope)
+            dy = _block_backward(dy.reshape(batch, seq_len_q, features), self._norm2, self._dropout2,
+                                 self._norm_first, cross_attention_backward, optimizer_, scope)
+            dy = _block_backward(dy, self._norm1, self._dropout1, self._norm_first, self_attention_backward,
+                                 optimizer_, scope)
+        return dy, kv_grad[0]

@@ -1,33 +1,32 @@
-"""Optimizers with the reference's call contract (reference optimizer.py:12-69).
+"""Optimizers under the reference's call contract (reference optimizer.py:12-69).
 
-A layer calls ``optimizer_.update(layer, '_w', grad)`` once per parameter; ``update`` looks
-the parameter up, lets ``update_variable`` change it IN PLACE and stores it back.  The
-reference's own unchanged ``optimizer.py`` also drives the device layers (``DeviceArray``
-implements ``lr * grad`` and ``-=``); these classes are the same contract for machines
-where the reference is not on the path, with the SGD step as a single device axpy.
-Adam keeps the reference's numerics -- epsilon INSIDE the square root, bias correction,
-fp64 moments keyed by ``f'{id(obj)}.{attribute}'``.  When parameter and gradient live on the
-device the whole update is one kernel (``npm_adam_step``) on device-resident fp64 moments;
-host arrays take the NumPy path.
+Contract, as the layers use it: ``optimizer_.update(layer, '_w', grad)`` once per parameter at the end of
+``backward``; the optimizer fetches the parameter with ``getattr``, changes it IN PLACE (aliases taken before the
+backward must see the new values) and stores it back with ``setattr``.  The reference's own, unchanged
+``optimizer.py`` drives the device layers just as well (``DeviceArray`` implements ``lr * grad`` and ``-=``); the
+classes here are the same contract for machines where the reference is not importable, with
+
+* SGD as one device ``axpy`` per parameter (``lr * grad`` stays symbolic until ``-=`` consumes it), and
+* Adam as one kernel per parameter (``npm_adam_step``) on fp64 moments resident in HBM, with the reference's
+  numerics: bias-corrected moments, epsilon INSIDE the square root, state keyed by ``f'{id(obj)}.{attribute}'``.
+  Host arrays take an equivalent NumPy path.
 """
 
 from __future__ import annotations
 
-import abc
-import dataclasses
-
 import numpy as np
 
 
-class Optimizer(metaclass=abc.ABCMeta):
-    def update(self, obj: object, attribute: str, gradient) -> None:
-        key = f'{id(obj)}.{attribute}'
-        updated = self.update_variable(key, getattr(obj, attribute), gradient)
-        setattr(obj, attribute, updated)
+class Optimizer:
+    """``update`` is what layers call; subclasses implement ``update_variable``."""
 
-    @abc.abstractmethod
+    def update(self, obj: object, attribute: str, gradient) -> None:
+        slot = f'{id(obj)}.{attribute}'
+        setattr(obj, attribute, self.update_variable(slot, getattr(obj, attribute), gradient))
+
     def update_variable(self, identifier: str, variable, gradient):
-        """Return the updated variable (mutated in place)."""
+        """Apply one step to ``variable`` in place and return it."""
+        raise NotImplementedError
 
 
 class SGDOptimizer(Optimizer):
@@ -35,71 +34,83 @@ class SGDOptimizer(Optimizer):
         self._learning_rate = learning_rate
 
     def update_variable(self, identifier, variable, gradient):
-        step = self._learning_rate * gradient      # DeviceArray -> symbolic; consumed by one axpy
-        variable -= step
+        variable -= self._learning_rate * gradient        # device operands: a single axpy kernel
         return variable
 
 
-@dataclasses.dataclass
-class AdamOptimizerConfig:
-    learning_rate: float
-    beta1: float = 0.9
-    beta2: float = 0.999
-    epsilon: float = 1e-7
+class _HostMoments:
+    """Adam state of one parameter on the host (fp64, like the reference's np.zeros defaults)."""
 
-    def __post_init__(self, *args, **kwargs):
-        self._steps = {}
-        self._momentums = {}
-        self._velocities = {}
+    def __init__(self, shape):
+        self.first = np.zeros(shape)
+        self.second = np.zeros(shape)
 
 
 class _DeviceMoments:
-    """fp64 first/second moments of one parameter, resident in HBM."""
+    """Adam state of one parameter in HBM: two fp64 vectors."""
 
-    def __init__(self, n: int):
+    def __init__(self, count: int):
         from np_modeling_amd import _C, device as D
-        self.n = n
-        self.m = D._Buffer(8 * n)
-        self.v = D._Buffer(8 * n)
-        _C.check(_C.lib().npm_fill_f64(self.m.ptr, 0.0, n), 'npm_fill_f64')
-        _C.check(_C.lib().npm_fill_f64(self.v.ptr, 0.0, n), 'npm_fill_f64')
+        self.count = count
+        self.first, self.second = D._Buffer(8 * count), D._Buffer(8 * count)
+        for buf in (self.first, self.second):
+            _C.check(_C.lib().npm_fill_f64(buf.ptr, 0.0, count), 'npm_fill_f64')
 
 
-class AdamOptimizer(AdamOptimizerConfig, Optimizer):
-    def _device_step(self, identifier, variable, gradient):
-        from np_modeling_amd import _C, device as D
-        if isinstance(gradient, D.Scaled):
-            gradient = gradient.materialize()
-        step = self._steps.get(identifier, 1)
-        state = self._momentums.get(identifier)
-        if not isinstance(state, _DeviceMoments) or state.n != variable.size:
-            state = _DeviceMoments(variable.size)
-        _C.check(_C.lib().npm_adam_step(variable.ptr, gradient.ptr, state.m.ptr, state.v.ptr, variable.size,
-                                        float(self.learning_rate), float(self.beta1), float(self.beta2),
-                                        float(self.epsilon), int(step)), 'npm_adam_step')
-        self._steps[identifier] = step + 1
-        self._momentums[identifier] = state
-        self._velocities[identifier] = state
-        return variable
+class AdamOptimizer(Optimizer):
+    """Adam as reference optimizer.py:36-69 computes it.  Positional order of the constructor: learning rate,
+    beta1, beta2, epsilon."""
+
+    def __init__(self, learning_rate: float, beta1: float = 0.9, beta2: float = 0.999, epsilon: float = 1e-7):
+        self.learning_rate, self.beta1, self.beta2, self.epsilon = learning_rate, beta1, beta2, epsilon
+        self._state = {}          # identifier -> [next step number (from 1), moments]
+
+    def _entry(self, identifier, make):
+        entry = self._state.get(identifier)
+        if entry is None or not make(entry[1]):
+            entry = self._state[identifier] = [1, make(None)]
+        return entry
 
     def update_variable(self, identifier, variable, gradient):
         from np_modeling_amd import device as D
-        if isinstance(variable, D.DeviceArray) and isinstance(gradient, (D.DeviceArray, D.Scaled)) \
-                and gradient.size == variable.size:
-            return self._device_step(identifier, variable, gradient)
-        grad = np.asarray(gradient, dtype=np.float64)
-        step = self._steps.get(identifier, 1)
-        first = self._momentums.get(identifier)
-        second = self._velocities.get(identifier)
-        if first is None:
-            first = np.zeros(grad.shape)
-            second = np.zeros(grad.shape)
-        first = self.beta1 * first + (1 - self.beta1) * grad
-        second = self.beta2 * second + (1 - self.beta2) * grad ** 2
-        first_hat = first / (1 - self.beta1 ** step)
-        second_hat = second / (1 - self.beta2 ** step)
-        variable -= self.learning_rate * (first_hat / np.sqrt(second_hat + self.epsilon))
-        self._steps[identifier] = step + 1
-        self._momentums[identifier] = first
-        self._velocities[identifier] = second
+        on_device = isinstance(variable, D.DeviceArray) and isinstance(gradient, (D.DeviceArray, D.Scaled)) \
+            and gradient.size == variable.size
+        if on_device:
+            return self._step_on_device(identifier, variable, gradient)
+        return self._step_on_host(identifier, variable, np.asarray(gradient, dtype=np.float64))
+
+    def _step_on_device(self, identifier, variable, gradient):
+        from np_modeling_amd import _C, device as D
+        if isinstance(gradient, D.Scaled):
+            gradient = gradient.materialize()
+        count = variable.size
+
+        def make(old):          # reuse matching state, else (re)create it
+            if old is None:
+                return _DeviceMoments(count)
+            return isinstance(old, _DeviceMoments) and old.count == count
+
+        entry = self._entry(identifier, make)
+        moments = entry[1]
+        _C.check(_C.lib().npm_adam_step(variable.ptr, gradient.ptr, moments.first.ptr, moments.second.ptr, count,
+                                        float(self.learning_rate), float(self.beta1), float(self.beta2),
+                                        float(self.epsilon), int(entry[0])), 'npm_adam_step')
+        entry[0] += 1
+        return variable
+
+    def _step_on_host(self, identifier, variable, grad):
+        def make(old):
+            if old is None:
+                return _HostMoments(grad.shape)
+            return isinstance(old, _HostMoments) and old.first.shape == grad.shape
+
+        entry = self._entry(identifier, make)
+        step, moments = entry
+        b1, b2 = self.beta1, self.beta2
+        moments.first = b1 * moments.first + (1.0 - b1) * grad
+        moments.second = b2 * moments.second + (1.0 - b2) * np.square(grad)
+        unbiased_first = moments.first / (1.0 - b1 ** step)
+        unbiased_second = moments.second / (1.0 - b2 ** step)
+        variable -= self.learning_rate * (unbiased_first / np.sqrt(unbiased_second + self.epsilon))
+        entry[0] = step + 1
         return variable

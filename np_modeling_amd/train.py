@@ -1,38 +1,40 @@
-"""Sequential trainer with the reference's interface (reference train.py:13-46)."""
+"""Sequential trainer with the interface and the printed output of reference train.py:13-46 (``Step:`` / ``Loss:``
+lines, which the golden loss trajectories are parsed from).  Activations and gradients stay on the device from the
+first layer to the loss and back; only the scalar loss comes to the host."""
 
 from __future__ import annotations
 
 import logging
 from typing import Optional, Sequence
 
-from np_modeling_amd import loss as loss_lib
-from np_modeling_amd import optimizer
-from np_modeling_amd.layers import layer
+from np_modeling_amd import loss as losses
+from np_modeling_amd.layers.layer import Layer
 
-_LOG = logging.getLogger(__name__)
+log = logging.getLogger(__name__)
 
 
 class Trainer:
-    def __init__(self, layers: Sequence[layer.Layer], loss_: Optional[loss_lib.Loss] = None):
+    def __init__(self, layers: Sequence[Layer], loss_: Optional['losses.Loss'] = None):
+        self._loss = losses.MSELoss() if loss_ is None else loss_
         self._layers = layers
-        self._loss = loss_ or loss_lib.MSELoss()
 
-    def _forward(self, inputs):
-        activation = inputs
-        for layer_ in self._layers:
-            _LOG.debug('forward %s', layer_.name)
-            activation = layer_(activation)
-        return activation
+    def _predict(self, batch):
+        for stage in self._layers:
+            log.debug('forward: %s', stage.name)
+            batch = stage(batch)
+        return batch
 
-    def train(self, inputs, targets, steps: int, optimizer_: optimizer.Optimizer) -> None:
-        for step in range(steps):
-            print('Step: ', step)
-            value = self._loss(self._forward(inputs), targets)
-            print('Loss: ', value)
-            grad = self._loss(backprop=True)
-            for layer_ in reversed(self._layers):
-                _LOG.debug('backward %s', layer_.name)
-                grad = layer_(grad, backprop=True, optimizer_=optimizer_)
+    def _backpropagate(self, optimizer_) -> None:
+        grad = self._loss(backprop=True)
+        for stage in self._layers[::-1]:
+            log.debug('backward: %s', stage.name)
+            grad = stage(grad, backprop=True, optimizer_=optimizer_)
+
+    def train(self, inputs, targets, steps: int, optimizer_) -> None:
+        for index in range(steps):
+            print('Step: ', index)
+            print('Loss: ', self._loss(self._predict(inputs), targets))
+            self._backpropagate(optimizer_)
 
     def eval(self, inputs, targets) -> None:
-        print('Loss: ', self._loss(self._forward(inputs), targets))
+        print('Loss: ', self._loss(self._predict(inputs), targets))
