@@ -12,7 +12,7 @@ inline int grid_for(size_t n, int cap = 4096) {
 }
 
 // reference optimizer.py:53-67 -- fp64 moments, bias correction, epsilon INSIDE the square root,
-// the fp64 update rounded to the parameter's fp32 when it is subtracted in place.
+// the subtraction itself in fp64 (NumPy's `f32 -= f64` runs the fp64 loop) and ONE rounding to the fp32 parameter.
 __global__ void __launch_bounds__(256)
 adam_kernel(float *__restrict__ var, const float *__restrict__ grad, double *__restrict__ m, double *__restrict__ v,
             size_t n, double lr, double beta1, double beta2, double eps, double corr1, double corr2) {
@@ -23,7 +23,7 @@ adam_kernel(float *__restrict__ var, const float *__restrict__ grad, double *__r
         m[i] = nm;
         v[i] = nv;
         const double step = lr * ((nm / corr1) / sqrt(nv / corr2 + eps));
-        var[i] = var[i] - (float)step;           // numpy: float32 -= float64 array -> cast, then subtract
+        var[i] = (float)((double)var[i] - step);  // numpy: float32 -= float64 array runs the fp64 loop and rounds ONCE
     }
 }
 

@@ -179,7 +179,18 @@ class DeviceArray:
         return self.copy()
 
     def __deepcopy__(self, memo):
-        return self.copy()
+        """Copies the OWNING pool block once per deepcopy (through ``memo``) and rebases this view into the copy:
+        views that shared a block still share one afterwards -- the packed q/k/v projection parameters stay
+        adjacent, and pointer views used as strided GEMM operands keep everything they address."""
+        key = ('np_modeling_amd._Buffer', id(self._buf))
+        buf = memo.get(key)
+        if buf is None:
+            buf = _Buffer(self._buf.nbytes)
+            if self._buf.nbytes:
+                _C.check(_C.lib().npm_d2d(buf.ptr, self._buf.ptr, self._buf.nbytes), 'npm_d2d')
+            memo[key] = buf
+            memo[id(buf)] = buf                  # keeps `buf` alive for the duration of the deepcopy
+        return DeviceArray(self.shape, buf, buf.ptr + (self.ptr - self._buf.ptr))
 
     def astype(self, dtype, copy=True):
         if np.dtype(dtype) == np.float32:

@@ -118,7 +118,8 @@ class MultiHeadAttention(layer.StatefulLayer):
             qkv = D.empty([b, sq, 3, h, dk])
             D.gemm(b * sq, 3 * f, f, Mat(query, f), Mat(wq, f), Mat(qkv, 3 * f), trans_b=True, bias=bq)
             pitch = 3 * f
-            q, k, v = qkv, qkv.flat_view(f, [1]), qkv.flat_view(2 * f, [1])
+            # k and v are the same buffer entered f and 2f elements later (row pitch 3f); the views span to the end
+            q, k, v = qkv, qkv.flat_view(f, [qkv.size - f]), qkv.flat_view(2 * f, [qkv.size - 2 * f])
         else:
             pitch = None
             q = D.empty([b, sq, h, dk])
@@ -204,7 +205,7 @@ class MultiHeadAttention(layer.StatefulLayer):
             dwq, dwk, dwv = (dw_all.flat_view(i * h * dk * f, [h, dk, f]) for i in range(3))
             dbq, dbk, dbv = (db_all.flat_view(i * h * dk, [h, dk]) for i in range(3))
             dqkv = D.empty([b, sq, 3, h, dk])
-            dq, dk_, dv_ = dqkv, dqkv.flat_view(f, [1]), dqkv.flat_view(2 * f, [1])
+            dq, dk_, dv_ = dqkv, dqkv.flat_view(f, [dqkv.size - f]), dqkv.flat_view(2 * f, [dqkv.size - 2 * f])
             gq = gk = gv = 3 * f
         else:
             dwq, dwk, dwv = scope.take(wq.shape), scope.take(wk.shape), scope.take(wv.shape)

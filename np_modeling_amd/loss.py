@@ -26,18 +26,12 @@ class Loss(layer.Layer):
     def backward(self, *args, **kwargs):
         pass
 
-    _cached_targets = None
-
     def _device_targets(self, targets, shape):
-        """Targets are usually the same host array every step: upload once."""
+        """Host targets are read afresh at every forward, as the reference does (a caller may refill the same
+        array in place between steps); ``Trainer.train`` uploads them once before its loop instead."""
         if isinstance(targets, D.DeviceArray):
             return targets
-        cached = self._cached_targets
-        if cached is not None and cached[0] is targets:
-            return cached[1]
-        dev = D.from_host(np.broadcast_to(np.asarray(targets, dtype=np.float32), shape))
-        self._cached_targets = (targets, dev)
-        return dev
+        return D.from_host(np.broadcast_to(np.asarray(targets, dtype=np.float32), shape))
 
 
 class MSELoss(Loss):

@@ -234,6 +234,7 @@ class GradScope:
         self._bucket: Optional[D.DeviceArray] = None
         self._offset = 0
         self._flushed = 0
+        self._started = False          # an all-reduce of this scope has been issued
         self._loose: List[D.DeviceArray] = []
         self._updates: List[Tuple[object, object, str, object]] = []
 
@@ -252,6 +253,18 @@ class GradScope:
         GradScope._active = None
         if exc_type is None:
             self._finish()
+        else:
+            # all-reduces started by flush() may still be writing the bucket on the communication stream, and the
+            # pool is stream-ordered for the COMPUTE stream only: drain both before the storage goes back to it
+            comm = communicator()
+            if comm.active and self._started:
+                try:
+                    comm.wait()
+                    D.synchronize()
+                except Exception:          # the original exception is the one to report
+                    pass
+            self._updates = []
+            self._bucket = None
         return False
 
     @property
@@ -283,9 +296,11 @@ class GradScope:
             return
         if root._bucket is not None and root._offset > root._flushed:
             begin = root._flushed
+            root._started = True
             comm.allreduce_async(root._bucket.flat_view(begin, [root._offset - begin]), _REDUCE_OP)
             root._flushed = root._offset
         for g in root._loose:
+            root._started = True
             comm.allreduce_async(g.reshape(-1), _REDUCE_OP)
         root._loose = []
 

@@ -31,10 +31,17 @@ class Trainer:
             grad = stage(grad, backprop=True, optimizer_=optimizer_)
 
     def train(self, inputs, targets, steps: int, optimizer_) -> None:
+        inputs, targets = self._resident(inputs), self._resident(targets)     # one upload for the whole loop
         for index in range(steps):
             print('Step: ', index)
             print('Loss: ', self._loss(self._predict(inputs), targets))
             self._backpropagate(optimizer_)
+
+    @staticmethod
+    def _resident(array):
+        """A device copy of a host array, made ONCE per call (the arguments are fixed for the duration of a call)."""
+        from np_modeling_amd import device as D
+        return D.as_device(array)
 
     def eval(self, inputs, targets) -> None:
         print('Loss: ', self._loss(self._predict(inputs), targets))

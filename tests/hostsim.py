@@ -272,7 +272,7 @@ class HostSim:
         vv[:] = beta2 * vv + (1 - beta2) * g ** 2
         upd = lr * ((mm / (1 - beta1 ** step)) / np.sqrt(vv / (1 - beta2 ** step) + eps))
         w = _vec(var, n)
-        w -= upd.astype(np.float32)
+        w -= upd                                            # fp64 loop, one rounding (as NumPy's f32 -= f64)
         return 0
 
     def npm_mse_fwd(self, y, t, n, out):

@@ -215,3 +215,120 @@ def test_mha_c4_slice(npm, exact_modes):
             assert np.abs(full[k]).max() < bound and np.abs(acc[k]).max() < bound
             continue
         assert_close(full[k], acc[k], tol=2e-5, what=k)
+
+
+def test_dense_c1(npm, exact_modes):
+    """BASELINE configs[0]: Dense(512 -> 512), batch 64 -- the whole layer against the oracle."""
+    D = npm.device
+    rng = np.random.default_rng(4)
+    layer = npm.layers.Dense(units=512)
+    x = rng.standard_normal([64, 512], dtype=np.float32)
+    dy = rng.standard_normal([64, 512], dtype=np.float32)
+    layer(D.from_host(np.zeros([1, 512], dtype=np.float32)))
+    w = (np.clip(rng.standard_normal([512, 512]), -1, 1) / np.sqrt(512)).astype(np.float32)
+    b = np.clip(rng.standard_normal([512]), -1, 1).astype(np.float32)
+    layer.linear._w.set(w)
+    layer.linear._b.set(b)
+    y = layer(x)
+    want_y, pre = O.dense_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64))
+    assert_close(y, want_y, tol=2e-6)
+    rec = GradRecorder()
+    dx = layer(dy, backprop=True, optimizer_=rec)
+    wdx, wdw, wdb = O.dense_bwd(x.astype(np.float64), w.astype(np.float64), pre, dy.astype(np.float64))
+    grads = {k[1]: np.asarray(v) for k, v in rec.grads.items()}
+    safe = ~(np.abs(pre) < 2e-6).any(axis=1)            # rows whose ReLU branch cannot differ from the fp64 oracle's
+    assert safe.mean() > 0.9
+    assert_close(np.asarray(dx)[safe], wdx[safe], tol=2e-6)
+    if safe.all():
+        assert_close(grads['_w'], wdw, tol=2e-6)
+        assert_close(grads['_b'], wdb, tol=2e-6)
+
+
+def test_conv_c3_slice(npm):
+    """BASELINE configs[2] at FULL size: Conv2D(64 -> 128, k = 3) on x[256, 224, 224, 64] (y is 6.6 GB, 12.8 M
+    pixels: the 32-bit descriptor arithmetic of csrc/npm_conv.hip meets its largest offsets here).  Convolution is
+    per sample, so the first, a middle and the LAST sample (highest addresses) of the full-size run are compared
+    whole -- image-border rows and columns included -- with the oracle at batch 1 (reference conv.py:44-61,74-194);
+    the filter and bias gradients, which sum over all 12.8 M pixels, must equal the sum over two batch halves run
+    on their own (other base addresses, other pixel indices), and a one-hot dy probe pins the filter gradient of
+    the last sample to the oracle.  Runs under the exact-f32 MFMA and the split-bf16 mode on the same data."""
+    D = npm.device
+    n, hw, c0, c1, k = 256, 224, 64, 128, 3
+    rng = np.random.default_rng(5)
+    layer = npm.layers.Conv2D(channels=c1, kernel_size=k)
+    layer(D.from_host(np.zeros([1, 4, 4, c0], dtype=np.float32)))
+    w = (np.clip(rng.standard_normal([k, k, c0, c1]), -1, 1) / np.sqrt(k * k * c0)).astype(np.float32)
+    b = np.clip(rng.standard_normal([c1]), -1, 1).astype(np.float32)
+    layer._w.set(w)
+    layer._b.set(b)
+    # distinct data in every sample, drawn one sample at a time (bounded host memory)
+    x_dev, dy_dev = D.empty([n, hw, hw, c0]), D.empty([n, hw, hw, c1])
+    picks = (0, 131, n - 1)
+    kept = {}
+    per_x, per_y = hw * hw * c0, hw * hw * c1
+    for s in range(n):
+        xs = rng.standard_normal([hw, hw, c0], dtype=np.float32)
+        ds = rng.standard_normal([hw, hw, c1], dtype=np.float32) * np.float32(0.01)
+        x_dev.flat_view(s * per_x, [hw, hw, c0]).set(xs)
+        dy_dev.flat_view(s * per_y, [hw, hw, c1]).set(ds)
+        if s in picks:
+            kept[s] = (xs, ds)
+    w64, b64 = w.astype(np.float64), b.astype(np.float64)
+    want = {}
+    for s in picks:
+        xs, ds = kept[s]
+        want_y, want_pre = O.conv_layer_fwd(xs[None].astype(np.float64), w64, b64)
+        want_dx, _, _ = O.conv_layer_bwd(xs[None].astype(np.float64), w64, want_pre, ds[None].astype(np.float64))
+        # ReLU's derivative is discontinuous: a pre-activation within fp32 rounding of 0 may take the other branch
+        # than in the fp64 oracle, which changes dx in its k x k neighbourhood; those pixels are left out
+        near = (np.abs(want_pre[0]) < 4e-6).any(axis=-1)
+        grown = near.copy()
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                grown |= np.roll(np.roll(near, di, axis=0), dj, axis=1)
+        assert grown.mean() < 0.02
+        # the border rows / columns stay part of the comparison
+        assert not grown[0].all() and not grown[-1].all() and not grown[:, 0].all() and not grown[:, -1].all()
+        want[s] = (want_pre, want_dx, grown)
+    probe = np.zeros([hw, hw, c1], dtype=np.float32)
+    probe[:, :, 5] = 1.0
+    want_probe = O.conv2d_grad_w(probe[None].astype(np.float64), kept[n - 1][0][None].astype(np.float64), k)
+
+    try:
+        for mode in ('f32', 'bf16x3'):
+            npm.set_math(mode)
+            rec = GradRecorder()
+            y = layer(x_dev)
+            pre = layer._activation._x
+            dx = layer(dy_dev, backprop=True, optimizer_=rec)
+            full = {key[1]: np.asarray(v).astype(np.float64) for key, v in rec.grads.items()}
+            for s in picks:
+                want_pre, want_dx, grown = want[s]
+                got_pre = pre.flat_view(s * per_y, [1, hw, hw, c1]).numpy()
+                got_y = y.flat_view(s * per_y, [1, hw, hw, c1]).numpy()
+                assert_close(got_pre, want_pre, tol=3e-6, what=f'{mode} pre[{s}]')
+                np.testing.assert_array_equal(got_y, np.maximum(got_pre, 0))
+                got_dx = dx.flat_view(s * per_x, [1, hw, hw, c0]).numpy()
+                assert_close(got_dx[0][~grown], want_dx[0][~grown], tol=3e-6, what=f'{mode} dx[{s}]')
+            del y, dx, pre
+            # filter / bias gradients: full batch == sum of the two halves run separately
+            acc = {}
+            half = n // 2
+            for lo in (0, half):
+                r = GradRecorder()
+                layer(x_dev.flat_view(lo * per_x, [half, hw, hw, c0]))
+                layer(dy_dev.flat_view(lo * per_y, [half, hw, hw, c1]), backprop=True, optimizer_=r)
+                for key, v in r.grads.items():
+                    acc[key[1]] = acc.get(key[1], 0) + np.asarray(v).astype(np.float64)
+            assert_close(full['_w'], acc['_w'], tol=2e-5, what=f'{mode} dw additivity')
+            assert_close(full['_b'], acc['_b'], tol=2e-5, what=f'{mode} db additivity')
+            # an independent anchor for the filter gradient at the highest addresses: with dy = 1 on ONE channel of
+            # every pixel of the LAST sample (0 elsewhere), dw is the shifted-window sum of that sample's x
+            gprobe = D.zeros([n, hw, hw, c1])
+            gprobe.flat_view((n - 1) * per_y, [hw, hw, c1]).set(probe)
+            dwp = D.empty([k, k, c0, c1])
+            npm._C.check(npm._C.lib().npm_conv2d_bwd_w(gprobe.ptr, x_dev.ptr, dwp.ptr, n, hw, hw, c0, c1, k))
+            assert_close(dwp, want_probe, tol=2e-5, what=f'{mode} dw probe (last sample)')
+            del gprobe
+    finally:
+        npm.set_math('f32')

@@ -250,6 +250,31 @@ def test_mha_reference_test_shape_vs_oracle(npm, math_mode):
         assert_close(getattr(layer, '_' + n), p[n] - 0.01 * grads[n], tol=1e-5, what=n)
 
 
+def test_mha_deepcopy_after_packed_forward(npm):
+    """attentions_test.py:72 on the PACKED self-attention path (default-initialised parameters, one q/k/v GEMM):
+    the cached k and v are views into the packed buffer; a deep copy made between forward and backward must give
+    the original layer's backward bit for bit, and the copied encoder likewise."""
+    np.random.seed(5)
+    layer = npm.layers.MultiHeadAttention(num_heads=4)
+    x, dy = rand([3, 20, 64]), rand([3, 20, 64])
+    layer(x)
+    assert layer._packed
+    twin = copy.deepcopy(layer)
+    assert twin._params_adjacent()
+    got = [np.asarray(g) for g in twin(dy, backprop=True, learning_rate=0.1)]
+    want = [np.asarray(g) for g in layer(dy, backprop=True, learning_rate=0.1)]
+    for a, b in zip(got, want):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+    for n in _MHA:
+        np.testing.assert_array_equal(np.asarray(getattr(twin, '_' + n)), np.asarray(getattr(layer, '_' + n)))
+    enc = npm.layers.TransformerEncoder(num_heads=4, hidden_units=96, norm_first=True)
+    enc(x)
+    twin = copy.deepcopy(enc)
+    np.testing.assert_array_equal(np.asarray(twin(dy, backprop=True, learning_rate=0.1)),
+                                  np.asarray(enc(dy, backprop=True, learning_rate=0.1)))
+
+
 def test_mha_mask_conventions(npm):
     layer = npm.layers.MultiHeadAttention(num_heads=2)
     q = rand([2, 4, 8])

@@ -259,3 +259,42 @@ def test_unique_id_exchange_under_launcher():
     out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     assert out.returncode == 0, out.stdout
     assert 'rank 0/2: id ok' in out.stdout and 'rank 1/2: id ok' in out.stdout, out.stdout
+
+
+def test_deepcopy_after_packed_forward(npm):
+    """reference layers/attentions_test.py:72 deep-copies the layer between forward and backward.  With the packed
+    q/k/v projection the cached k and v are views INTO the packed buffer: the copy must keep everything the strided
+    GEMMs address, and parameter views of one block must stay adjacent."""
+    import copy
+    np.random.seed(0)
+    layer = npm.layers.MultiHeadAttention(num_heads=2)
+    x, dy = rand([2, 6, 8]), rand([2, 6, 8])
+    layer(x)                                          # default-initialised parameters: the packed path
+    assert layer._packed
+    twin = copy.deepcopy(layer)
+    assert twin._params_adjacent() and twin._wq.ptr != layer._wq.ptr
+    got = [np.asarray(g) for g in twin(dy, backprop=True, learning_rate=0.1)]
+    want = [np.asarray(g) for g in layer(dy, backprop=True, learning_rate=0.1)]
+    for a, b in zip(got, want):
+        assert np.isfinite(a).all()
+        np.testing.assert_array_equal(a, b)
+    for n in ('_wq', '_wk', '_wv', '_wo', '_bq', '_bk', '_bv', '_bo'):
+        np.testing.assert_array_equal(np.asarray(getattr(twin, n)), np.asarray(getattr(layer, n)))
+    # and an encoder copied after its forward
+    enc = npm.layers.TransformerEncoder(num_heads=2, hidden_units=12, norm_first=True)
+    enc(x)
+    twin = copy.deepcopy(enc)
+    np.testing.assert_array_equal(np.asarray(twin(dy, backprop=True, learning_rate=0.1)),
+                                  np.asarray(enc(dy, backprop=True, learning_rate=0.1)))
+
+
+def test_loss_reads_refilled_targets(npm):
+    """A caller may refill the SAME host array between steps (targets[:] = next_batch); the reference reads it
+    afresh at every forward (loss.py:21-25)."""
+    D = npm.device
+    y = D.from_host(np.ones([4, 3], dtype=np.float32))
+    targets = np.zeros([4, 3], dtype=np.float32)
+    mse = npm.loss.MSELoss()
+    assert mse(y, targets) == pytest.approx(1.0)
+    targets[:] = 1.0
+    assert mse(y, targets) == pytest.approx(0.0)
