@@ -4,10 +4,13 @@ batch 256 per GPU (BASELINE.json configs[4]; U = 4096 hidden units, pre-norm, SU
 
     python bench.py --gpus N --steps K --warmup W
 
-N = 1 runs in this process; for N > 1 the driver launches one rank per GPU with
-``python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...`` and the ranks
-join an RCCL group (batch sharded: every rank runs the per-GPU batch, weak scaling; the
-parameter gradients are all-reduced over xGMI inside ``backward``).
+N = 1 runs in this process.  For N > 1 every rank is its own process on its own GPU: either an
+external launcher starts them (the driver: ``python -m torch.distributed.run --nproc-per-node N
+... bench.py --gpus N ...``; RANK / LOCAL_RANK / WORLD_SIZE in the environment), or plain
+``python bench.py --gpus N`` starts N fresh child processes itself (np_modeling_amd/launch.py)
+before anything touches a GPU.  The ranks join an RCCL group (batch sharded: every rank runs the
+per-GPU batch, weak scaling; the parameter gradients are all-reduced over xGMI inside
+``backward``); the 128-byte RCCL id travels through a file -- the product imports no torch.
 
 A step = forward + backward + the SGD update of every parameter, on synthetic fp32 tensors
 already resident in HBM.  Rank 0 prints ONE JSON line (contract in the task description) with
@@ -129,12 +132,14 @@ def main():
                     help="skip the second timed region that repeats the K steps with --math bf16x3 ('alt_math' in the JSON)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        # Plain `python bench.py --gpus N`: this process becomes the launcher.  It has not touched the GPU (nothing
+        # above imports the device library) and never will: the N ranks are FRESH child processes.
+        from np_modeling_amd import launch
+        sys.exit(launch.spawn_ranks(args.gpus, [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
-    if args.gpus != world:
-        if args.gpus > 1 and world == 1:
-            raise SystemExit('bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)')
-        args.gpus = world
+    args.gpus = world                                    # under a launcher its environment is authoritative
 
     import np_modeling_amd as npm
     from np_modeling_amd import device as D, parallel
@@ -206,6 +211,10 @@ def main():
         'step_tflops_per_gpu': value / world * fps / 1e12,
         'step_frac_of_fp32_mfma_peak': value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS,
     }
+    if comm.active:
+        result['exchange'] = {'library': parallel.RcclCommunicator.library_path(), 'reduce': 'avg',
+                              'launcher': 'external (RANK/WORLD_SIZE in the environment)' if 'NPM_RENDEZVOUS_FILE' not in os.environ
+                              else 'np_modeling_amd.launch (self-launched child ranks)', 'torch_imported': 'torch' in sys.modules}
 
     if timer is not None:
         summary = timer.summary()

@@ -7,8 +7,8 @@
  * Layer.backward's gradient computation and optimizer_.update (reference call sites
  * layers/mlp.py:38-39, layers/normalizations.py:73-74, layers/attentions.py:190-197).
  *
- * One process per GPU.  Rank 0 creates the id, the launcher's store carries it to the
- * other ranks (host side: np_modeling_amd/parallel.py), every rank calls npm_comm_init.
+ * One process per GPU.  Rank 0 creates the id, a file of the node carries it to the other
+ * ranks (host side: np_modeling_amd/parallel.py rendezvous_path), every rank calls npm_comm_init.
  * Collectives run on a dedicated communication stream so they overlap the rest of the
  * backward pass; ordering against the compute stream is by HIP events.
  */
@@ -26,6 +26,10 @@ extern "C" {
 enum { NPM_REDUCE_SUM = 0, NPM_REDUCE_AVG = 1, NPM_REDUCE_MAX = 2 };
 
 const char *npm_comm_last_error(void);
+/* File the RCCL entry points of this process were bound from (the shim is linked against /opt/rocm/lib/librccl.so
+ * by rpath; a host program that had ALREADY loaded another librccl.so.1 -- e.g. the copy bundled with PyTorch --
+ * would make the dynamic linker reuse that one: this call tells which, bench.py reports it). */
+int npm_comm_library_path(char *buf, int len);
 int npm_comm_unique_id(char *id /* NPM_COMM_ID_BYTES */);
 /* compute_stream: npm_stream() of libnpm_hip.so (the stream gradients are produced on) */
 int npm_comm_init(const char *id, int rank, int nranks, void *compute_stream);

@@ -112,6 +112,7 @@ _SPECIAL = {
 }
 
 COMM_SIGNATURES = {
+    'npm_comm_library_path': [C.c_char_p, C.c_int],
     'npm_comm_unique_id': [C.c_char_p],
     'npm_comm_init': [C.c_char_p, C.c_int, C.c_int, _P],
     'npm_comm_rank': [C.POINTER(C.c_int), C.POINTER(C.c_int)],
@@ -141,18 +142,33 @@ def _bind(cdll, signatures, special):
     return cdll
 
 
-def _build_if_missing(path: str) -> None:
-    """The shared libraries are build artefacts (git-ignored).  If they are absent and the ROCm
-    compiler is present, build them in tree once -- still no CPU fallback: no compiler, no library."""
-    if os.path.exists(path) or os.environ.get('NPM_NO_AUTOBUILD') == '1':
+def build_if_missing() -> None:
+    """The shared libraries are build artefacts (git-ignored).  If one is absent and the ROCm compiler is present,
+    build them in tree -- still no CPU fallback: no compiler, no library.  Serialised across processes by a file
+    lock (N ranks importing the package at once must not run ``make`` concurrently); a launcher calls this before
+    it starts the ranks (np_modeling_amd/launch.py)."""
+    if (os.path.exists(LIB_PATH) and os.path.exists(RCCL_LIB_PATH)) or os.environ.get('NPM_NO_AUTOBUILD') == '1':
         return
+    import fcntl
     import shutil
     import subprocess
     hipcc = os.environ.get('HIPCC') or shutil.which('hipcc') or '/opt/rocm/bin/hipcc'
     if not os.path.exists(hipcc):
         return
-    subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j4', f'HIPCC={hipcc}'], check=False,
-                   stdout=subprocess.DEVNULL)
+    os.makedirs(LIB_DIR, exist_ok=True)
+    with open(os.path.join(LIB_DIR, '.build.lock'), 'w') as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if os.path.exists(LIB_PATH) and os.path.exists(RCCL_LIB_PATH):      # another process built them meanwhile
+            return
+        proc = subprocess.run(['make', '-C', os.path.join(_HERE, 'csrc'), '-j4', f'HIPCC={hipcc}'],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if proc.returncode != 0:
+            raise NpmError('building the HIP libraries failed:\n' + proc.stdout[-4000:])
+
+
+def _build_if_missing(path: str) -> None:
+    if not os.path.exists(path):
+        build_if_missing()
 
 
 def load_library(path: str = LIB_PATH):

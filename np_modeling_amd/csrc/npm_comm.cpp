@@ -8,6 +8,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <dlfcn.h>
 #include <unistd.h>
 
 #include "npm_comm.h"
@@ -80,6 +81,14 @@ ncclRedOp_t to_op(int op) {
 extern "C" {
 
 const char *npm_comm_last_error(void) { return g_err; }
+
+int npm_comm_library_path(char *buf, int len) {
+    if (!buf || len < 2) return fail(-1, "npm_comm_library_path: bad buffer");
+    Dl_info info;
+    if (!dladdr((void *)&ncclAllReduce, &info) || !info.dli_fname) return fail(-1, "npm_comm_library_path: dladdr failed");
+    snprintf(buf, (size_t)len, "%s", info.dli_fname);
+    return 0;
+}
 
 int npm_comm_unique_id(char *id) {
     if (!id) return fail(-1, "npm_comm_unique_id: null id");

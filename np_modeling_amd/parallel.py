@@ -6,9 +6,10 @@ exchange step (section 8e): between a layer's gradient computation and its
 attentions.py:190-197) the parameter gradients are all-reduced over RCCL/xGMI.
 
 Design
-* one process per GPU (``torch.distributed.run`` sets RANK/LOCAL_RANK/WORLD_SIZE);
-  the 128-byte RCCL id travels through the launcher's TCP store -- the only use of
-  torch in the product, and only when WORLD_SIZE > 1;
+* one process per GPU, described by RANK / LOCAL_RANK / WORLD_SIZE in the environment -- set by
+  the self-launcher (np_modeling_amd/launch.py: fresh child processes, no third-party runtime) or
+  by any external one-process-per-GPU launcher; the 128-byte RCCL id travels from rank 0 to
+  the others through a file of this node (:func:`rendezvous_path`);
 * gradients of one backward are carved out of ONE flat device bucket
   (:class:`GradScope`), so the exchange is a few large all-reduces issued on a separate
   communication stream as soon as each sub-layer's gradients exist (overlapping the rest
@@ -75,6 +76,13 @@ class RcclCommunicator(Communicator):
         _C.check_comm(self._lib.npm_comm_init(unique_id, rank, world_size, stream), 'npm_comm_init')
 
     @staticmethod
+    def library_path() -> str:
+        """The librccl.so this process is bound to (include/npm_comm.h npm_comm_library_path)."""
+        buf = C.create_string_buffer(1024)
+        _C.check_comm(_C.comm_lib().npm_comm_library_path(buf, 1024), 'npm_comm_library_path')
+        return buf.value.decode()
+
+    @staticmethod
     def new_unique_id() -> bytes:
         buf = C.create_string_buffer(128)
         _C.check_comm(_C.comm_lib().npm_comm_unique_id(buf), 'npm_comm_unique_id')
@@ -106,22 +114,59 @@ _COMM: Optional[Communicator] = None
 _REDUCE_OP = AVG
 
 
-def _exchange_unique_id(rank: int, world_size: int) -> bytes:
-    """Carry rank 0's RCCL id to the other ranks through the launcher's TCP store."""
-    from torch.distributed import TCPStore      # plumbing only; imported only when world_size > 1
-    import datetime
-    addr = os.environ.get('MASTER_ADDR', '127.0.0.1')
-    port = int(os.environ['MASTER_PORT'])
-    agent_store = os.environ.get('TORCHELASTIC_USE_AGENT_STORE', '').lower() == 'true'
-    store = TCPStore(addr, port, world_size, is_master=(rank == 0 and not agent_store),
-                     timeout=datetime.timedelta(seconds=300), wait_for_workers=False)
-    key = 'np_modeling_amd/rccl_id/' + os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
+def _launch_token() -> str:
+    """Identifies ONE launch of the ranks of this node: they are children of the same launcher process (the
+    self-launcher of np_modeling_amd/launch.py, ``torch.distributed.run``'s agent, a shell), so its pid plus its start
+    time (field 22 of /proc/<pid>/stat; pids are recycled, start times are not) is the same for every rank of
+    the launch and different from every other launch."""
+    ppid = os.getppid()
+    try:
+        with open(f'/proc/{ppid}/stat') as f:
+            started = f.read().rsplit(')', 1)[1].split()[19]
+    except (OSError, IndexError):
+        started = '0'
+    return f'{ppid}-{started}'
+
+
+def rendezvous_path() -> str:
+    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of this node.  ``NPM_RENDEZVOUS_FILE`` (set by
+    the self-launcher) names it outright; under an external launcher it is derived from the launch token, the
+    master port and the restart count, so concurrent or earlier jobs never share a file."""
+    explicit = os.environ.get('NPM_RENDEZVOUS_FILE')
+    if explicit:
+        return explicit
+    import tempfile
+    parts = [str(os.getuid()), os.environ.get('MASTER_PORT', '0'), _launch_token(),
+             os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')]
+    return os.path.join(tempfile.gettempdir(), 'npm_rccl_id.' + '.'.join(parts))
+
+
+def _exchange_unique_id(rank: int, world_size: int, timeout: float = 300.0) -> bytes:
+    """Carry rank 0's RCCL id to the other ranks of the node through a file: rank 0 writes it under a temporary
+    name and renames it into place (readers see all 128 bytes or nothing); the others poll.  No third-party
+    runtime is involved -- the product path imports neither torch nor an MPI."""
+    import time
+    path = rendezvous_path()
     if rank == 0:
         uid = RcclCommunicator.new_unique_id()
-        store.set(key, uid)
-    else:
-        uid = bytes(store.get(key))
-    return uid
+        assert len(uid) == 128
+        tmp = f'{path}.{os.getpid()}.tmp'
+        with open(tmp, 'wb') as f:
+            f.write(uid)
+        os.replace(tmp, path)
+        return uid
+    deadline = time.monotonic() + timeout
+    while True:
+        try:
+            with open(path, 'rb') as f:
+                uid = f.read()
+            if len(uid) == 128:
+                return uid
+        except FileNotFoundError:
+            pass
+        if time.monotonic() > deadline:
+            raise _C.NpmError(f'rank {rank}: no RCCL id from rank 0 at {path} after {timeout:.0f} s')
+        time.sleep(0.01)
 
 
 def init(reduce: str = 'avg') -> Communicator:
@@ -136,8 +181,14 @@ def init(reduce: str = 'avg') -> Communicator:
         _COMM = Communicator()
         return _COMM
     _C.lib()                                             # bind this process to cuda:LOCAL_RANK first
-    uid = _exchange_unique_id(rank, world) if 'MASTER_PORT' in os.environ else RcclCommunicator.new_unique_id()
+    uid = _exchange_unique_id(rank, world) if world > 1 else RcclCommunicator.new_unique_id()
     _COMM = RcclCommunicator(rank, world, uid)
+    if world > 1 and rank == 0 and not os.environ.get('NPM_RENDEZVOUS_FILE'):
+        # ncclCommInitRank is collective: every rank has read the id by now (a self-launcher removes its own file)
+        try:
+            os.unlink(rendezvous_path())
+        except OSError:
+            pass
     return _COMM
 
 

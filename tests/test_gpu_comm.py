@@ -86,3 +86,29 @@ def test_rccl_init_keeps_stdout_clean():
     out = subprocess.run([sys.executable, '-c', code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-2000:]
     assert out.stdout.strip().splitlines() == ['only-this-line'], out.stdout
+
+
+def test_self_launched_rank_runs_the_exchange_path():
+    """`python -m np_modeling_amd.launch --gpus 1 bench.py ...` with NPM_FORCE_RCCL=1: the spawned-rank path end to
+    end on one GPU -- a fresh child process, an RCCL communicator bound to /opt/rocm's librccl (no torch in the
+    process), the flat-bucket all-reduce inside backward, and ONE JSON line on stdout."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NPM_FORCE_RCCL='1')
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'NPM_RENDEZVOUS_FILE'):
+        env.pop(key, None)
+    cmd = [sys.executable, '-m', 'np_modeling_amd.launch', '--gpus', '1', os.path.join(root, 'bench.py'), '--gpus', '1',
+           '--steps', '2', '--warmup', '1', '--batch', '4', '--seq', '64', '--features', '128', '--heads', '4',
+           '--hidden', '256', '--no-cpu-baseline', '--no-alt-math']
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, out.stdout
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 1 and line['value'] > 0
+    assert line['exchange']['library'].startswith('/opt/rocm'), line['exchange']
+    assert line['exchange']['torch_imported'] is False
+    assert 'self-launched' in line['exchange']['launcher']

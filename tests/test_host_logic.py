@@ -247,18 +247,73 @@ def test_data_parallel_equivalence_gloo():
     assert 'encoder_post' in outs[0]
 
 
-def test_unique_id_exchange_under_launcher():
-    """The RCCL id rendezvous with two ranks under the launcher the driver uses for N > 1
-    (python -m torch.distributed.run, agent store on 127.0.0.1)."""
-    port = _free_port()
+def _clean_env(**extra):
     env = dict(os.environ, OMP_NUM_THREADS='1')
-    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+    env.update(NPM_NO_AUTOBUILD='1', **extra) if 'NPM_NO_AUTOBUILD' not in extra else env.update(extra)
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'NPM_RENDEZVOUS_FILE'):
         env.pop(key, None)
+    return env
+
+
+def test_self_launcher_rendezvous_two_ranks(capfd):
+    """np_modeling_amd/launch.py: two FRESH child ranks, the RCCL id travels from rank 0 to rank 1 through the
+    launcher's private file, no torch anywhere in the product path."""
+    from np_modeling_amd import launch
+    code = launch.spawn_ranks(2, [sys.executable, os.path.join(ROOT, 'tests', 'uid_worker.py')], build=False,
+                              env=_clean_env())
+    out = capfd.readouterr()
+    assert code == 0, out.err
+    assert 'rank 0/2: id ok' in out.out and 'rank 1/2: id ok' in out.err      # rank 0 owns stdout, the rest stderr
+
+
+def test_self_launcher_reports_a_failing_rank(capfd):
+    """A rank that exits non-zero ends the job with its code; the ranks still running are terminated."""
+    import time
+    from np_modeling_amd import launch
+    t0 = time.monotonic()
+    code = launch.spawn_ranks(3, [sys.executable, os.path.join(ROOT, 'tests', 'uid_worker.py')], build=False,
+                              env=_clean_env(UID_WORKER_FAIL_RANK='1', UID_WORKER_HANG='1'))
+    assert code == 7
+    assert time.monotonic() - t0 < 60                 # did not wait for the ranks that sleep 120 s
+    assert 'rank 1 exited with code 7' in capfd.readouterr().err
+
+
+def test_launcher_module_cli():
+    out = subprocess.run([sys.executable, '-m', 'np_modeling_amd.launch', '--gpus', '2',
+                          os.path.join(ROOT, 'tests', 'uid_worker.py')], env=_clean_env(), cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=240)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip() == 'rank 0/2: id ok'
+
+
+def test_unique_id_exchange_under_torch_launcher():
+    """The same rendezvous under the launcher the driver uses for N > 1 (python -m torch.distributed.run): the
+    ranks are children of one agent process, which is what the derived rendezvous path keys on."""
+    port = _free_port()
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '2',
            '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.join(ROOT, 'tests', 'uid_worker.py')]
-    out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
+    out = subprocess.run(cmd, env=_clean_env(), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=240)
     assert out.returncode == 0, out.stdout
     assert 'rank 0/2: id ok' in out.stdout and 'rank 1/2: id ok' in out.stdout, out.stdout
+
+
+def test_bench_gpus_n_becomes_a_launcher_before_touching_the_gpu():
+    """`python bench.py --gpus 2` as a plain command starts child ranks (reference: none -- SURVEY 8e is new
+    functionality).  Without a GPU the ranks fail loudly in npm_init and the launcher reports that code; what
+    is checked here is the process structure: two ranks were started with RANK / WORLD_SIZE set."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '1', '--warmup', '0',
+                          '--no-cpu-baseline'], env=_clean_env(NPM_NO_AUTOBUILD='0'), cwd=ROOT,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    import ctypes
+    from np_modeling_amd import _C
+    count = ctypes.c_int(0)
+    _C.load_library().npm_device_count(ctypes.byref(count))
+    if count.value >= 2:
+        assert out.returncode == 0, out.stderr[-3000:]
+        assert '"n_gpus": 2' in out.stdout
+    else:
+        assert out.returncode != 0
+        assert 'np_modeling_amd.launch: rank' in out.stderr and 'no CPU fallback' in out.stderr, out.stderr[-3000:]
 
 
 def test_deepcopy_after_packed_forward(npm):
