@@ -35,6 +35,7 @@ import numpy as np  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # same guide: v_mfma_f32_32x32x16_bf16, dense (16x the f32 MFMA rate)
 HBM_PEAK_GBS = 8000.0
+MFMA_BOUND = ('sgemm_', 'mha_core_')    # kernel-timer names of the MFMA-bound family: GEMMs and the fused attention core
 
 
 def encoder_flops_per_sample(seq, feat, heads, hidden):
@@ -218,14 +219,15 @@ def main():
 
     if timer is not None:
         summary = timer.summary()
-        gemm = {k: v for k, v in summary.items() if k.startswith('sgemm_')}
+        gemm = {k: v for k, v in summary.items() if k.startswith(MFMA_BOUND)}
         g_ms = sum(v['ms'] for v in gemm.values())
         g_flops = sum(v['flops'] for v in gemm.values())
         g_launches = sum(v['launches'] for v in gemm.values())
         achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         traffic, traffic_src = load_pmc_traffic(args)
         result['roofline'] = {
-            'kernel': ('sgemm_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family, LDS-DMA pipeline: NN/NT/TN)' if args.math == 'f32' else
+            'kernel': ('fp32 v_mfma_f32_32x32x2_f32 family: sgemm_glds_kernel (LDS-DMA pipeline, NN/NT/TN) and the fused attention core '
+                       'mha_fwd_kernel / mha_bwd_kernel (algorithmic FLOPs: 2 + 4 products; a recomputed q.k is not counted)' if args.math == 'f32' else
                        f'sgemm_glds_kernel ({args.math}: six v_mfma_f32_32x32x16_bf16 per fp32 product; achieved counts fp32-equivalent '
                        'FLOPs against the f32 MFMA peak, the bf16 pipe executes 6x that)'),
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -238,7 +240,7 @@ def main():
                               'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in sorted(gemm.items())},
             'hbm_kernels': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],
                                 'GBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
-                            for k, v in sorted(summary.items()) if not k.startswith('sgemm_') and v['ms'] > 0},
+                            for k, v in sorted(summary.items()) if not k.startswith(MFMA_BOUND) and v['ms'] > 0},
         }
     if args.math == 'f32' and not args.no_alt_math:
         # Second timed region, same K steps, same barriers: the matrix products on the bf16 pipe (three-way operand

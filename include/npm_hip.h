@@ -124,6 +124,7 @@ enum {
     NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, -1 unbalanced ceil(3 CUs / tiles) */
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */
     NPM_TUNE_GEMM_MATH = 10,         /* same as npm_set_math */
+    NPM_TUNE_ATTN_STAGGER = 11,      /* attention forward: s_sleep(127) units one of the two blocks of a CU waits at its start (default 1) */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);
@@ -194,6 +195,41 @@ int npm_conv2d_bwd_x(const float *dy, const float *filt, float *dx,
 /* dw[i,j] = shifted(x)^T dy  (conv.py:185-194) */
 int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
                      int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
+
+/* ---- fused attention core (layers/attentions.py:103-112 forward, :146-162 backward) ----
+ * ctx[b, i, h, :] = sum_j softmax_j(scale * q[b, i, h, :] . k[b, j, h, :]) v[b, j, h, :] in ONE kernel: the
+ * [B, H, Sq, Skv] probabilities never go to memory (online softmax, as derived in the reference's
+ * layers/attentions_test.py:158-265); the forward saves lse[b, h, i] = log sum_j exp(scale * q.k) and the backward
+ * recomputes the probabilities from it.  q/k/v/ctx and the gradients are [B, S, H, D] with a row pitch (H * D, or
+ * 3 * H * D inside a packed qkv buffer); head_dim in {16, 32, 64, 128}, else NPM_E_UNSUPPORTED (callers then
+ * compose the same math from npm_sgemm + npm_softmax_*).  mask (optional): bytes, element (b, h, i, j) at
+ * mask[b * stride_b + h * stride_h + i * stride_q + j], 0 = excluded (np.where(mask, scaled, -inf),
+ * attentions.py:105-107); the backward treats excluded positions as P = 0 (the reference raises NotImplementedError
+ * there, attentions.py:152-153).  scores (optional, [B, H, Sq, Skv]): when given, the forward also stores the raw
+ * masked scores q.k and the backward reads them instead of recomputing q.k (trades 4 B/element of traffic each way
+ * for one of the five matrix products).  fp32 MFMA only (npm_set_math does not apply to this kernel). */
+typedef struct npm_mha_core {
+    int32_t batch, heads, seq_q, seq_kv, head_dim;
+    float scale;                                   /* 1 / sqrt(Dk), > 0 */
+    const float *q; int64_t q_pitch;
+    const float *k; int64_t k_pitch;
+    const float *v; int64_t v_pitch;
+    const uint8_t *mask; int64_t mask_stride_b, mask_stride_h, mask_stride_q;
+    float *ctx; int64_t ctx_pitch;                 /* forward: out; backward: in (the forward's result) */
+    float *lse;                                    /* [B, H, Sq]; forward: out; backward: in */
+    float *scores;                                 /* optional [B, H, Sq, Skv]; forward: out; backward: in */
+    const float *dctx; int64_t dctx_pitch;         /* backward only from here */
+    float *dq; int64_t dq_pitch;
+    float *dk; int64_t dk_pitch;
+    float *dv; int64_t dv_pitch;
+} npm_mha_core;
+int npm_mha_core_supported(int head_dim);          /* 1 when npm_mha_core_fwd/bwd take this head dimension */
+int npm_mha_core_fwd(const npm_mha_core *c);
+int npm_mha_core_bwd(const npm_mha_core *c);
+/* Diagnostics: when buf != NULL every block of the backward kernel writes 16 words of s_memtime stamps of ONE of its
+ * tiles (phase boundaries: tile start, after S, dP, dV, dK, the dS barrier, dQ, the dQ stores; word 8: next tile's start)
+ * to buf[blockIdx * 16 ..]; NULL switches it off. */
+int npm_debug_attn_trace(long long *buf);
 
 /* ---- around the path ("next" rows of SURVEY.md section 8f): keeps a Trainer step on the device ---- */
 /* Adam with the reference's numerics (optimizer.py:53-67): fp64 moments m, v (device buffers of n doubles,

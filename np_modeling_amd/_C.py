@@ -52,6 +52,24 @@ class npm_conv2d(C.Structure):
     ]
 
 
+class npm_mha_core(C.Structure):
+    _fields_ = [
+        ('batch', C.c_int32), ('heads', C.c_int32), ('seq_q', C.c_int32), ('seq_kv', C.c_int32), ('head_dim', C.c_int32),
+        ('scale', C.c_float),
+        ('q', C.c_void_p), ('q_pitch', C.c_int64),
+        ('k', C.c_void_p), ('k_pitch', C.c_int64),
+        ('v', C.c_void_p), ('v_pitch', C.c_int64),
+        ('mask', C.c_void_p), ('mask_stride_b', C.c_int64), ('mask_stride_h', C.c_int64), ('mask_stride_q', C.c_int64),
+        ('ctx', C.c_void_p), ('ctx_pitch', C.c_int64),
+        ('lse', C.c_void_p),
+        ('scores', C.c_void_p),
+        ('dctx', C.c_void_p), ('dctx_pitch', C.c_int64),
+        ('dq', C.c_void_p), ('dq_pitch', C.c_int64),
+        ('dk', C.c_void_p), ('dk_pitch', C.c_int64),
+        ('dv', C.c_void_p), ('dv_pitch', C.c_int64),
+    ]
+
+
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK, EPI_RELU, EPI_SOFTMAX_BWD = 1, 2, 4, 8, 16, 32
 
 _P, _SZ, _I64, _I32, _F = C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_float
@@ -81,6 +99,7 @@ SIGNATURES = {
     'npm_set_math': [C.c_int],
     'npm_get_math': [],
     'npm_debug_gemm_trace': [_P],
+    'npm_debug_attn_trace': [_P],
     'npm_relu_fwd': [_P, _P, _SZ],
     'npm_relu_bwd': [_P, _P, _P, _SZ],
     'npm_add': [_P, _P, _P, _SZ],
@@ -97,6 +116,9 @@ SIGNATURES = {
     'npm_conv2d_fwd': [C.POINTER(npm_conv2d)],
     'npm_conv2d_bwd_x': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
     'npm_conv2d_bwd_w': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
+    'npm_mha_core_supported': [C.c_int],
+    'npm_mha_core_fwd': [C.POINTER(npm_mha_core)],
+    'npm_mha_core_bwd': [C.POINTER(npm_mha_core)],
     'npm_adam_step': [_P, _P, _P, _P, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int],
     'npm_fill_f64': [_P, C.c_double, _SZ],
     'npm_mse_fwd': [_P, _P, _SZ, C.POINTER(C.c_double)],
@@ -215,12 +237,22 @@ def lib():
 MATH_MODES = {'f32': 0, 'bf16x3_fast': 1, 'bf16x3': 2}      # include/npm_hip.h NPM_MATH_*
 
 
+_MATH = 'f32'
+
+
+def current_math() -> str:
+    """The math mode last set through :func:`set_math` (no library call)."""
+    return _MATH
+
+
 def set_math(mode: str) -> None:
     """Arithmetic of the matrix products: 'f32' (exact-fp32 MFMA, default), 'bf16x3' (three-way bf16 operand split
     on the bf16 matrix pipe, fp32-class error) or 'bf16x3_fast' (same, one accumulator); include/npm_hip.h."""
     if mode not in MATH_MODES:
         raise ValueError(f'unknown math mode {mode!r}: expected one of {sorted(MATH_MODES)}')
+    global _MATH
     check(lib().npm_set_math(MATH_MODES[mode]), 'npm_set_math')
+    _MATH = mode
 
 
 def get_math() -> str:

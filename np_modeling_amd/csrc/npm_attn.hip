@@ -1,0 +1,787 @@
+// Fused scaled-dot-product attention core on the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32), forward and backward.
+//
+// Replaces, for one call each, the chain of reference layers/attentions.py:103-112 (QK^T einsum, 1/sqrt(Dk),
+// optional mask, Softmax.forward, PV einsum) and attentions.py:146-162 (dscores, dv, Softmax.backward, 1/sqrt(Dk),
+// dq, dk).  The [B,H,Sq,Skv] probability tensor never goes to memory: the forward keeps a running row maximum and
+// row sum (the blockwise online softmax the reference derives in layers/attentions_test.py:158-265) and saves one
+// log-sum-exp per query row; the backward recomputes P = exp(scale * q.k - LSE) tile by tile.
+//
+// Layout: q/k/v/ctx and their gradients stay [B, S, H, D] (row pitch given: H*D, or 3*H*D inside a packed qkv
+// buffer); a head is the column slice [h*D, (h+1)*D) of a row.  D in {16, 32, 64, 128}.
+//
+// MFMA orientation (one f32 per lane per operand: lane l supplies A[i = l & 31][k = l >> 5], B[k = l >> 5][j = l & 31];
+// the result has its column j on the lane and rows (r & 3) + 8 (r >> 2) + 4 (l >> 5) in registers r = 0..15):
+//   forward  S^T[kv, q] = K Q^T : the query is on the lane, so the softmax statistics of a row are lane-local (one
+//            cross-half exchange per reduction) and P^T is, register for register, the B operand of
+//            O^T[d, q] += V^T[d, kv] P^T[kv, q] -- no data movement between the two products.
+//   backward S[q, kv] and dP[q, kv] with the KEY on the lane: P and dS are then the B operands of
+//            dV^T[d, kv] += dO^T[d, q] P[q, kv] and dK^T[d, kv] += Q^T[d, q] dS[q, kv]; only dS crosses LDS, once,
+//            for dQ[q, d] += dS[q, kv] K[kv, d].
+// Operand tiles arrive by LDS-DMA (buffer_load_dwordx4 ... lds) with the bank swizzle applied on the SOURCE address.
+#include <algorithm>
+#include <cmath>
+
+#include "npm_mfma_tile.h"
+
+namespace {
+
+using npm_tile::f32x16;
+using npm_tile::lds_dma16;
+using npm_tile::xcd_remap;
+
+constexpr float LOG2E = 1.44269504088896340736f;
+constexpr float LN2 = 0.69314718055994530942f;
+constexpr int OOB = 0x7FFFFFFF;
+
+struct MhaArgs {
+    const float *q, *k, *v;
+    long q_pitch, k_pitch, v_pitch;
+    float *ctx;
+    long ctx_pitch;
+    float *lse;                       // [B, H, Sq]
+    float *delta;                     // backward scratch [B, H, Sq]: rowsum(dctx * ctx)
+    const float *dctx;
+    long dctx_pitch;
+    float *dq, *dk, *dv;
+    long dq_pitch, dk_pitch, dv_pitch;
+    const unsigned char *mask;        // optional, element (b, h, i, j) at mask[b sb + h sh + i sq + j]; 0 = masked out
+    long mask_sb, mask_sh, mask_sq;
+    float *scores;                    // optional [B, H, Sq, Skv]: raw (unscaled, masked) scores kept for the backward
+    int batch, heads, seq_q, seq_kv;
+    float scale;
+    int q_tiles;                      // forward: blocks per (b, h)
+    int stagger;                      // forward: s_sleep(127) units one of the two blocks of a CU waits at its start
+    long long *trace;                 // diagnostics (npm_debug_attn_trace): 16 s_memtime stamps per block, or null
+};
+
+// [rows][D] fp32 tile in LDS whose 16-byte chunk c of row r sits at chunk position c ^ (r & SWZ).  Rows read with
+// one ds_read_b128 per lane (lane = row: the K-major MFMA operand) are conflict-free (16 consecutive rows hit 16
+// different positions), and so are ds_read_b32 along a row (the XOR permutes chunks inside one 64-byte-aligned group).
+template <int D>
+struct Tile {
+    static constexpr int CPR = D / 4;                           // chunks per row
+    static constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
+    static constexpr int PIECE_ROWS = 256 / D;                  // rows per 1 KiB DMA piece
+    static constexpr int NG = D / 8;                            // k groups of 8 along a row
+    static constexpr int NB = NG < 8 ? NG : 8;                  // lane-dependent bases of the row reads
+    static_assert(D == 16 || D == 32 || D == 64 || D == 128, "head dim");
+    __device__ static __forceinline__ int chunk(int row, int c) { return row * D + ((c ^ (row & SWZ)) << 2); }
+    __device__ static __forceinline__ int elem(int row, int col) { return row * D + ((((col >> 2) ^ (row & SWZ)) << 2) | (col & 3)); }
+    // byte offset (inside a [rows][pitch] global matrix) that lane `lane` of DMA piece `piece` copies from
+    __device__ static __forceinline__ unsigned src(int lane, int piece, long pitch) {
+        const int row = piece * PIECE_ROWS + lane / CPR;
+        const int c = (lane % CPR) ^ (row & SWZ);
+        return (unsigned)((row * pitch + c * 4) * 4);
+    }
+    // Addresses as (lane-dependent base register) + (compile-time immediate), so that a fully unrolled phase costs a
+    // handful of address registers instead of one per read (hipcc hoists every distinct address out of the loop).
+    // Row read (ds_read_b128) of row l32 (+ a multiple of 16), group g: rb[g & 7] + row_imm(g).
+    __device__ static __forceinline__ void row_bases(int l32, int half, int (&rb)[NB]) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) rb[j] = chunk(l32, 2 * j + half);
+    }
+    __device__ static constexpr int row_imm(int g) { return (g >> 3) * 64; }      // chunk bit 4 is above the swizzle
+    // Column reads.  A lane reads VEC = D / 32 adjacent columns (one ds_read_b128 / b64 / b32) of row
+    // 4 half + (r & 3) + 8 (r >> 2), starting at column VEC * lane: vb[(r >> 2) & 1][r & 3] + vec_imm(r).  Element t
+    // of the vector belongs to MFMA tile t, whose row (or column) i = lane is head dimension VEC * lane + t.
+    static constexpr int VEC = D >= 32 ? D / 32 : 1;
+    __device__ static __forceinline__ void vec_bases(int half, int l32, int (&vb)[2][4]) {
+        const int col = VEC * (D < 32 ? (l32 & (D - 1)) : l32);
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) vb[par][k] = elem(4 * half + k + 8 * par, col);
+    }
+    __device__ static constexpr int vec_imm(int r) { return 16 * (r >> 3) * D; }
+    // Element read (ds_read_b32) of row 4 half + k + 8 rr, column 32 t + col (col < 32): eb[k] + elem_imm(t, rr).
+    __device__ static __forceinline__ void elem_bases(int half, int col, int (&eb)[4]) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) eb[k] = elem(4 * half + k, col);
+    }
+    __device__ static constexpr int elem_imm(int t, int rr) { return 8 * rr * D + (((8 * t) ^ ((8 * rr) & SWZ)) << 2); }
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+// VEC adjacent floats from LDS into v[0 .. VEC)
+template <int VEC>
+__device__ __forceinline__ void ldv(const float *p, float (&v)[4]) {
+    if (VEC == 4) { const float4 x = ld4(p); v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w; }
+    else if (VEC == 2) { const float2 x = *reinterpret_cast<const float2 *>(p); v[0] = x.x; v[1] = x.y; }
+    else v[0] = p[0];
+}
+__device__ __forceinline__ float xhalf(float x) { return __shfl_xor(x, 32, 64); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float4 buf_load4(__amdgpu_buffer_rsrc_t r, int voff) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+__device__ __forceinline__ void buf_store4(__amdgpu_buffer_rsrc_t r, int voff, float a, float b, float c, float d) {
+    u32x4_t v = {__float_as_uint(a), __float_as_uint(b), __float_as_uint(c), __float_as_uint(d)};
+    __builtin_amdgcn_raw_buffer_store_b128(v, r, voff, 0, 0);
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, long bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)std::min<long>(std::max<long>(bytes, 0), 0x7FFFFFF0L), 0x00020000);
+}
+
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+
+// Instruction-order hints for one phase of `steps` steps, each `reads` LDS reads feeding `mfmas` MFMAs: the reads
+// of step i + 1 are issued before the MFMAs of step i (one step of prefetch), nothing is hoisted further.  Without
+// them hipcc clusters every LDS read of a fully unrolled phase in front of its first MFMA (hundreds of live
+// registers, spills).  Masks: 0x100 DS read, 0x008 MFMA.
+template <int STEPS, int READS, int MFMAS>
+__device__ __forceinline__ void sched_pipeline() {
+    __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+#pragma unroll
+    for (int i = 0; i + 1 < STEPS; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x100, READS, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+    }
+    __builtin_amdgcn_sched_group_barrier(0x008, MFMAS, 0);
+}
+#define PHASE_END() __builtin_amdgcn_sched_barrier(0)
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+// diagnostics: stamp `slot` of this block's trace record (wave 0, one chosen tile); costs nothing when trace == null
+#define STAMP(slot) do { if (tr) { FENCE(); tr[slot] = __builtin_amdgcn_s_memtime(); FENCE(); } } while (0)
+
+__device__ __forceinline__ void zero16(f32x16 &x) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) x[e] = 0.f;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// What bounds these kernels (tools/microbench/mfma_f32_chain.hip, profiles/r02_mfma_f32_chain.log): v_mfma_f32_32x32x2
+// holds the SIMD's issue for its whole 64 cycles -- with one wave per SIMD every other instruction of that wave adds
+// its full issue time (about 7 cycles) to the tile, with two waves about half of that.  So the design rule is the
+// INSTRUCTION COUNT per MFMA: operands are read 16 bytes at a time wherever the layout allows (one LDS read per 4
+// MFMAs), addresses are register + immediate, global accesses use scalar offsets, and nothing is computed twice.
+// ---------------------------------------------------------------------------------------------------------------
+// Forward.  Block = 4 wavefronts = 128 query rows of one (batch, head); wave w owns rows 32 w .. 32 w + 31 with
+// its Q fragment (D / 2 registers) and O^T accumulators (D / 2 registers) resident.  K and V tiles of 32 keys
+// stream through two LDS stages; one barrier per tile; two blocks per CU.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool MASK, bool SAVE>
+__global__ void __launch_bounds__(256, 2)
+mha_fwd_kernel(const MhaArgs p) {
+    using T = Tile<D>;
+    constexpr int NG = D / 8, DT = (D + 31) / 32, VEC = T::VEC, TILE = 32 * D, PIECES = D / 8, PPW = (PIECES + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE];            // K stages 0/1, V stages 0/1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, half = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int qt = logical % p.q_tiles, bh = logical / p.q_tiles;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const int qrow = qt * 128 + wave * 32 + l32;                             // this lane's query
+    const bool qok = qrow < p.seq_q;
+
+    const auto rsrcK = make_rsrc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
+    const auto rsrcQ = make_rsrc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
+
+    // Q fragment: element s of group g is Q[qrow][8 g + 4 half + s]
+    float4 qf[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) qf[g] = buf_load4(rsrcQ, qok ? (int)((qrow * p.q_pitch + 8 * g + 4 * half) * 4) : OOB);
+
+    unsigned vk[PPW], vv[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        vk[i] = T::src(lane, wave * PPW + i, p.k_pitch);
+        vv[i] = T::src(lane, wave * PPW + i, p.v_pitch);
+    }
+    const unsigned kstep = (unsigned)(32 * p.k_pitch * 4), vstep = (unsigned)(32 * p.v_pitch * 4);
+    auto issue = [&](int t, int stage) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int j = wave * PPW + i;
+            if (j < PIECES) {                                                 // the row offset rides the VGPR offset: it is range-checked
+                lds_dma16(rsrcK, smem + stage * TILE + j * 256, vk[i] + t * kstep, 0);
+                lds_dma16(rsrcV, smem + (2 + stage) * TILE + j * 256, vv[i] + t * vstep, 0);
+            }
+        }
+    };
+
+    int rb[T::NB], vb[2][4];
+    T::row_bases(l32, half, rb);
+    T::vec_bases(half, l32, vb);
+
+    f32x16 O[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) zero16(O[t]);
+    float m = -INFINITY, l = 0.f;
+    const float c = p.scale * LOG2E;
+    const int nt = (p.seq_kv + 31) / 32;
+    const unsigned char *mrow = MASK ? p.mask + b * p.mask_sb + h * p.mask_sh + (long)qrow * p.mask_sq : nullptr;
+    float *srow = SAVE ? p.scores + ((long)bh * p.seq_q + qrow) * p.seq_kv : nullptr;
+
+    issue(0, 0);
+    // The two blocks of a CU run the same program; started together they reach their softmax (no MFMA) together and
+    // the matrix pipe idles.  Blocks b and b + 256 share a CU on a first dispatch: delay one of them by about half a
+    // tile, later generations inherit the offset.  (Placement is not guaranteed: this is for speed only.)
+    if (p.stagger && ((blockIdx.x >> 8) & 1)) {
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    for (int t = 0; t < nt; ++t) {
+        __syncthreads();                                // tile t has landed; nobody still reads the stage refilled next
+        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
+        const float *sK = smem + (t & 1) * TILE, *sV = smem + (2 + (t & 1)) * TILE;
+
+        // ---- S^T[kv, q] = K Q^T: NG steps of (1 row read, 4 MFMAs), every read one step ahead of its use
+        f32x16 S;
+        zero16(S);
+        float4 fk[2];
+        float ev[2][4];
+        fk[0] = ld4(sK + rb[0]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) fk[(g + 1) & 1] = ld4(sK + rb[(g + 1) & 7] + T::row_imm(g + 1));
+            else ldv<VEC>(sV + vb[0][0], ev[0]);                                 // first vector of the PV phase
+            FENCE();
+            S = MFMA(fk[g & 1].x, qf[g].x, S);
+            S = MFMA(fk[g & 1].y, qf[g].y, S);
+            S = MFMA(fk[g & 1].z, qf[g].z, S);
+            S = MFMA(fk[g & 1].w, qf[g].w, S);
+            FENCE();
+        }
+        const int kv0 = 32 * t + 4 * half;              // register r holds key kv0 + (r & 3) + 8 (r >> 2)
+        if (32 * t + 32 > p.seq_kv) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (kv0 + (r & 3) + 8 * (r >> 2) >= p.seq_kv) S[r] = -INFINITY;
+        }
+        if (MASK && qok) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int kv = kv0 + (r & 3) + 8 * (r >> 2);
+                if (kv < p.seq_kv && mrow[kv] == 0) S[r] = -INFINITY;
+            }
+        }
+        if (SAVE && qok) {
+#pragma unroll
+            for (int g4 = 0; g4 < 4; ++g4) {
+                const int kv = kv0 + 8 * g4;
+                if (kv + 3 < p.seq_kv) *reinterpret_cast<float4 *>(srow + kv) = make_float4(S[4 * g4], S[4 * g4 + 1], S[4 * g4 + 2], S[4 * g4 + 3]);
+                else
+                    for (int e = 0; e < 4; ++e)
+                        if (kv + e < p.seq_kv) srow[kv + e] = S[4 * g4 + e];
+            }
+        }
+        // ---- online softmax in the exp2 domain: the statistics of query `qrow` live on its two lanes
+        float tmax = S[0];
+#pragma unroll
+        for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
+        tmax = fmaxf(tmax, xhalf(tmax));
+        const float m_new = fmaxf(m, tmax * c);
+        const float alpha = fast_exp2(m - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            S[r] = fast_exp2(fmaf(S[r], c, -m_new));
+            psum += S[r];
+        }
+        psum += xhalf(psum);
+        l = fmaf(l, alpha, psum);
+        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {      // some row's maximum moved: rescale the accumulators
+#pragma unroll
+            for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) O[t2][e] *= alpha;
+        }
+        m = m_new;
+        FENCE();
+        // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]: 16 steps (one key row each) of (1 vector read, DT MFMAs);
+        //      tile t2 row `lane` is head dimension VEC lane + t2
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            if (r + 1 < 16) ldv<VEC>(sV + vb[((r + 1) >> 2) & 1][(r + 1) & 3] + T::vec_imm(r + 1), ev[(r + 1) & 1]);
+            FENCE();
+#pragma unroll
+            for (int t2 = 0; t2 < DT; ++t2) O[t2] = MFMA(ev[r & 1][t2], S[r], O[t2]);
+            FENCE();
+        }
+    }
+
+    const float inv = 1.f / l;
+    if (half == 0 && qok) p.lse[(long)bh * p.seq_q + qrow] = (m + __builtin_amdgcn_logf(l)) * LN2;       // v_log_f32 is log2
+    const auto rsrcC = make_rsrc(p.ctx + (long)b * p.seq_q * p.ctx_pitch + h * D, ((long)(p.seq_q - 1) * p.ctx_pitch + D) * 4);
+    // register r of the DT tiles together is VEC adjacent head dimensions, from VEC * (4 half + (r & 3) + 8 (r >> 2))
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d0 = VEC * (4 * half + (r & 3) + 8 * (r >> 2));
+        if (VEC * (8 * (r >> 2) + (r & 3)) < D) {                                // compile-time part of the bound (D = 16)
+            const int off = (qok && d0 < D) ? (int)((qrow * p.ctx_pitch + d0) * 4) : OOB;
+            if (VEC == 4) buf_store4(rsrcC, off, O[0][r] * inv, O[DT > 1 ? 1 : 0][r] * inv, O[DT > 2 ? 2 : 0][r] * inv, O[DT > 3 ? 3 : 0][r] * inv);
+            else
+#pragma unroll
+                for (int t2 = 0; t2 < DT; ++t2)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(O[t2][r] * inv), rsrcC, off == OOB ? OOB : off + 4 * t2, 0, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Backward.  One block = 4 wavefronts = one (batch, head); one block per CU (145 KB of LDS at D = 128, the whole
+// register file per wave).  Outer loop: key blocks of 128 (wave w owns keys 32 w .. 32 w + 31 of the block, its dK^T
+// and dV^T accumulators and its V fragment in registers, the K block in LDS); inner loop: query tiles of 32 (Q and
+// dO tiles by LDS-DMA, two stages).  dQ is summed over the key blocks by the SAME wave in program order (a plain
+// read-modify-write of its own 32 x 32 slice): no atomics, bitwise reproducible.
+// The row terms LSE (from the forward) and delta = rowsum(dO * O) (mha_delta_kernel, 8 B/element of [B,S,H,D]) are
+// read one tile ahead, one value per lane, and turned from "query on the lane" into "query in the registers" through LDS.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool MASK, bool SAVED>
+__global__ void __launch_bounds__(256, 1)
+mha_bwd_kernel(const MhaArgs p) {
+    using T = Tile<D>;
+    using TS = Tile<128>;
+    constexpr int NG = D / 8, DT = (D + 31) / 32, VEC = T::VEC, QTILE = 32 * D, KBLK = 128 * D;
+    constexpr int QPIECES = D / 8, QPPW = (QPIECES + 3) / 4, KPPW = D / 8;       // K block: D / 2 pieces, D / 8 per wave
+    __shared__ __attribute__((aligned(16))) float sKB[KBLK];
+    __shared__ __attribute__((aligned(16))) float sQ[2 * QTILE];
+    __shared__ __attribute__((aligned(16))) float sDO[2 * QTILE];
+    __shared__ __attribute__((aligned(16))) float sDS[32 * 128];
+    __shared__ float sRow[4 * 64];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l32 = lane & 31, half = lane >> 5;
+    const int dcol = D < 32 ? (l32 & (D - 1)) : l32;
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    float *xs = sRow + wave * 64;
+
+    const auto rsrcK = make_rsrc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
+    const auto rsrcQ = make_rsrc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
+    const auto rsrcDO = make_rsrc(p.dctx + (long)b * p.seq_q * p.dctx_pitch + h * D, ((long)(p.seq_q - 1) * p.dctx_pitch + D) * 4);
+    const auto rsrcDQ = make_rsrc(p.dq + (long)b * p.seq_q * p.dq_pitch + h * D, ((long)(p.seq_q - 1) * p.dq_pitch + D) * 4);
+    const auto rsrcDK = make_rsrc(p.dk + (long)b * p.seq_kv * p.dk_pitch + h * D, ((long)(p.seq_kv - 1) * p.dk_pitch + D) * 4);
+    const auto rsrcDV = make_rsrc(p.dv + (long)b * p.seq_kv * p.dv_pitch + h * D, ((long)(p.seq_kv - 1) * p.dv_pitch + D) * 4);
+    // an empty descriptor: every access through it is out of range (loads give 0, stores are dropped)
+    const auto rsrcNone = make_rsrc(p.dq, 0);
+    const float *lse = p.lse + (long)bh * p.seq_q, *dlt = p.delta + (long)bh * p.seq_q;
+
+    unsigned vq[QPPW], vdo[QPPW], vkb[KPPW];
+#pragma unroll
+    for (int i = 0; i < QPPW; ++i) {
+        vq[i] = T::src(lane, wave * QPPW + i, p.q_pitch);
+        vdo[i] = T::src(lane, wave * QPPW + i, p.dctx_pitch);
+    }
+#pragma unroll
+    for (int i = 0; i < KPPW; ++i) vkb[i] = T::src(lane, wave * KPPW + i, p.k_pitch);
+    const unsigned qstep = (unsigned)(32 * p.q_pitch * 4), dostep = (unsigned)(32 * p.dctx_pitch * 4);
+    // DMA piece i (0 .. 2 QPPW - 1) of this wave for tile qt: the Q pieces first, then the dO pieces.  A tile beyond
+    // the last one reads out of range (zeros into a stage nobody reads): no branch around the issue.
+    auto issue_piece = [&](int qt, int stage, int i) {
+        const int j = wave * QPPW + (i % QPPW);
+        if (j < QPIECES) {
+            if (i < QPPW) lds_dma16(rsrcQ, sQ + stage * QTILE + j * 256, vq[i % QPPW] + qt * qstep, 0);
+            else lds_dma16(rsrcDO, sDO + stage * QTILE + j * 256, vdo[i % QPPW] + qt * dostep, 0);
+        }
+    };
+    constexpr int NP = 2 * QPPW;               // DMA pieces per wave and tile
+
+    const float c = p.scale * LOG2E;
+    const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
+    const int kvl = 32 * wave + l32;                                             // this lane's key inside the block
+
+    // LDS addresses: lane-dependent bases + immediates (Tile<D>::row_bases / vec_bases / elem_bases)
+    int rb[T::NB], vb[2][4], rbs[TS::NB], ebk[2][4], ebs[2][4];
+    T::row_bases(l32, half, rb);                         // rows of the Q / dO tiles, and of this wave's K rows
+    T::vec_bases(half, l32, vb);                         // column vectors of the Q / dO tiles
+    TS::row_bases(l32, half, rbs);                       // rows of the dS tile
+    {
+        int eb[4], es[4];
+        T::elem_bases(half, dcol, eb);
+        TS::elem_bases(half, l32, es);
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                ebk[par][k] = eb[k] + (((8 * wave) ^ ((8 * par) & T::SWZ)) << 2);        // K block, columns 32 wave + ..
+                ebs[par][k] = es[k] + (((8 * wave) ^ ((8 * par) & TS::SWZ)) << 2);       // dS tile, columns 32 wave + ..
+            }
+    }
+    const float *sKW = sKB + 32 * wave * D;              // this wave's 32 keys of the K block
+
+    // dQ slice of this wave, held TRANSPOSED (dQ^T[d, q] = K^T dS^T): the query q0 + l32 is on the lane and register
+    // group r >> 2 is the 4 adjacent head dimensions 32 wave + 8 (r >> 2) + 4 half ..: the read-modify-write of the
+    // slice is 4 + 4 sixteen-byte accesses per tile instead of 16 + 16 dwords.  The lane part of the address is one
+    // register, the tile's first row a scalar offset (range-checked with it, as in the GEMM epilogue).
+    const bool dq_wave = wave < DT;
+    const int dq_voff = (int)((l32 * p.dq_pitch + 32 * wave + 4 * half) * 4);
+    const auto rsrcDQw = dq_wave ? rsrcDQ : rsrcNone;     // waves without a slice: every access out of range
+    // Key-block seams.  Nothing of the next key block waits at the seam: its K block and V fragment are requested in
+    // the LAST query tile of the current one (behind a barrier that says every wave is done with the K block, in
+    // front of that tile's 64 dK MFMAs), its first Q / dO tile -- tile 0 again -- is the regular "next tile" prefetch
+    // of that last tile, and this block's dK / dV stores stay in flight behind a counted wait.
+    auto issue_kblock = [&](int kb) {
+        const unsigned kboff = (unsigned)(kb * 128 * p.k_pitch * 4);
+#pragma unroll
+        for (int i = 0; i < KPPW; ++i) lds_dma16(rsrcK, sKB + (wave * KPPW + i) * 256, vkb[i] + kboff, 0);
+    };
+    float4 vf[NG];                                                               // V[key][8 g + 4 half + s] of the current block
+    auto load_vfrag = [&](int kb) {
+        const int row = kb * 128 + kvl;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) vf[g] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 8 * g + 4 * half) * 4) : OOB);
+    };
+    constexpr int SEAM_STORES = VEC == 4 ? 32 + 4 : 0;   // D = 128: 32 dK/dV stores + the last tile's 4 dQ stores stay in flight
+    issue_kblock(0);
+    load_vfrag(0);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) issue_piece(0, 0, i);
+    int it = 0;                                          // tiles done so far: stage parity
+    // Row terms of the next tile (one query per lane), fetched one tile ahead -- across the seams too
+    float lse_n = l32 < p.seq_q ? lse[l32] * LOG2E : 0.f, dlt_n = l32 < p.seq_q ? dlt[l32] : 0.f;
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int kvrow = kb * 128 + kvl;
+        const bool kvok = kvrow < p.seq_kv;
+        f32x16 dK[DT], dV[DT];
+#pragma unroll
+        for (int t = 0; t < DT; ++t) { zero16(dK[t]); zero16(dV[t]); }
+        const auto rsrcOld = kb > 0 ? rsrcDQw : rsrcNone;                        // first key block: "old" dQ reads as 0
+
+        int in_flight = kb > 0 ? SEAM_STORES : 0;        // youngest vector-memory operations that may stay outstanding
+
+        for (int qt = 0; qt < nqt; ++qt) {
+            // Tile qt (and the K block) has landed for every wave; the other stage and sDS are free.  The dQ stores
+            // of the previous tile are the youngest 4 vector-memory operations of this wave: they stay in flight.
+            if (in_flight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (in_flight == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool seam = qt + 1 == nqt && kb + 1 < nkb;      // last tile of a key block that has a successor
+            const int nq = qt + 1 < nqt ? qt + 1 : 0;             // the next tile to prefetch: wraps to the next block's tile 0
+            long long *tr = (p.trace && tid == 0 && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
+            if (p.trace && tid == 0 && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime(); FENCE(); }
+            STAMP(0);
+            const int cur = it & 1, nxt = cur ^ 1;
+            const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
+            const int q0 = 32 * qt;
+            // Row terms, from "query on the lane" to "query in the registers", through 256 bytes of LDS private to the
+            // wave; read back at once (a read inside a later phase would wait behind that phase's operand prefetch).
+            if (half == 0) { xs[l32] = lse_n; xs[32 + l32] = dlt_n; }
+            float Lr[16], Dr[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                Lr[r] = xs[4 * half + (r & 3) + 8 * (r >> 2)];
+                Dr[r] = xs[32 + 4 * half + (r & 3) + 8 * (r >> 2)];
+            }
+            {
+                const int nrow = 32 * nq + l32;
+                const bool nok = nrow < p.seq_q;
+                lse_n = nok ? lse[nrow] * LOG2E : 0.f;
+                dlt_n = nok ? dlt[nrow] : 0.f;
+            }
+            const int dq_tile = q0 * (int)p.dq_pitch * 4;                         // scalar: byte offset of the tile's first row
+            float4 dq_old[4];
+            f32x16 S, P, dP, dS;
+            float4 fa[2], fk[2];                       // row fragments, one step ahead
+            float ea[2][4];                            // column vectors, one step ahead
+            if (SAVED) {
+                const float *sc = p.scores + ((long)bh * p.seq_q) * p.seq_kv + kvrow;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = q0 + 4 * half + (r & 3) + 8 * (r >> 2);
+                    S[r] = (row < p.seq_q && kvok) ? sc[(long)row * p.seq_kv] : 0.f;
+                }
+#pragma unroll
+                for (int i = 0; i < NP; ++i) issue_piece(nq, nxt, i);
+                fa[0] = ld4(tDO + rb[0]);
+            } else {
+                // ---- S[q, kv] = Q K^T: NG steps of (2 row reads, 4 MFMAs), every read one step ahead of its use;
+                //      the next tile's DMA pieces are issued along the way
+                zero16(S);
+                fa[0] = ld4(tQ + rb[0]);
+                fk[0] = ld4(sKW + rb[0]);
+#pragma unroll
+                for (int g = 0; g < NG; ++g) {
+                    if (g + 1 < NG) {
+                        fa[(g + 1) & 1] = ld4(tQ + rb[(g + 1) & 7] + T::row_imm(g + 1));
+                        fk[(g + 1) & 1] = ld4(sKW + rb[(g + 1) & 7] + T::row_imm(g + 1));
+                    } else {
+                        fa[(g + 1) & 1] = ld4(tDO + rb[0]);                       // first fragment of the next phase
+                    }
+#pragma unroll
+                    for (int i = g * NP / NG; i < (g + 1) * NP / NG; ++i) issue_piece(nq, nxt, i);
+                    FENCE();
+                    S = MFMA(fa[g & 1].x, fk[g & 1].x, S);
+                    S = MFMA(fa[g & 1].y, fk[g & 1].y, S);
+                    S = MFMA(fa[g & 1].z, fk[g & 1].z, S);
+                    S = MFMA(fa[g & 1].w, fk[g & 1].w, S);
+                    FENCE();
+                }
+            }
+            STAMP(1);
+            // ---- dP[q, kv] = dO V^T (V fragment in registers); the old dQ values are fetched along the way
+            constexpr int F0 = SAVED ? 0 : (NG & 1);   // parity slot that holds dO fragment 0
+            zero16(dP);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                if (g + 1 < NG) fa[(F0 + g + 1) & 1] = ld4(tDO + rb[(g + 1) & 7] + T::row_imm(g + 1));
+                else ldv<VEC>(tDO + vb[0][0], ea[0]);                                 // first vector of the next phase
+                if (g < 4 && 8 * g < D) {              // old dQ^T values of head dimensions 8 g + 4 half .. of this wave's slice
+                    const u32x4_t o = __builtin_amdgcn_raw_buffer_load_b128(rsrcOld, dq_voff + 32 * g, dq_tile, 0);
+                    dq_old[g] = make_float4(__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w));
+                }
+                FENCE();
+                dP = MFMA(fa[(F0 + g) & 1].x, vf[g].x, dP);
+                dP = MFMA(fa[(F0 + g) & 1].y, vf[g].y, dP);
+                dP = MFMA(fa[(F0 + g) & 1].z, vf[g].z, dP);
+                dP = MFMA(fa[(F0 + g) & 1].w, vf[g].w, dP);
+                FENCE();
+            }
+            // ---- P = exp(scale S - LSE); dS = scale P (dP - delta), also into LDS for the dQ product
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float pr = fast_exp2(fmaf(S[r], c, -Lr[r]));
+                if (MASK) {
+                    const int qr = q0 + 4 * half + (r & 3) + 8 * (r >> 2);
+                    if (qr < p.seq_q && kvok && p.mask[b * p.mask_sb + h * p.mask_sh + (long)qr * p.mask_sq + kvrow] == 0) pr = 0.f;
+                }
+                P[r] = pr;
+                dS[r] = pr * (dP[r] - Dr[r]) * p.scale;
+                sDS[ebs[(r >> 2) & 1][r & 3] + 8 * (r >> 2) * 128] = dS[r];
+            }
+            STAMP(2);
+            // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 16 steps (one query row each) of (1 vector read, DT MFMAs);
+            //      tile t row `lane` is head dimension VEC lane + t
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r + 1 < 16) ldv<VEC>(tDO + vb[((r + 1) >> 2) & 1][(r + 1) & 3] + T::vec_imm(r + 1), ea[(r + 1) & 1]);
+                FENCE();
+#pragma unroll
+                for (int t = 0; t < DT; ++t) dV[t] = MFMA(ea[r & 1][t], P[r], dV[t]);
+                FENCE();
+            }
+            STAMP(3);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                      // dS of all four key groups is in LDS
+            asm volatile("" ::: "memory");
+            STAMP(4);
+
+            // ---- dQ[q, d] (+)= dS[q, kv] K[kv, d] over the 128 keys of the block; wave w takes the columns 32 w .. 32 w + 31
+            f32x16 acc;
+            if (dq_wave) {
+                zero16(acc);
+                float4 da[2];
+                float dk4[2][4];
+                da[0] = ld4(sDS + rbs[0]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) dk4[0][k] = sKB[ebk[0][k]];
+#pragma unroll
+                for (int g = 0; g < 16; ++g) {
+                    if (g + 1 < 16) {
+                        da[(g + 1) & 1] = ld4(sDS + rbs[(g + 1) & 7] + TS::row_imm(g + 1));
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dk4[(g + 1) & 1][k] = sKB[8 * (g + 1) * D + ebk[(g + 1) & 1][k]];
+                    } else {
+                        ldv<VEC>(tQ + vb[0][0], ea[0]);                               // first vector of the next phase
+                    }
+                    FENCE();
+                    acc = MFMA(dk4[g & 1][0], da[g & 1].x, acc);      // transposed: rows = head dimension, column = query
+                    acc = MFMA(dk4[g & 1][1], da[g & 1].y, acc);
+                    acc = MFMA(dk4[g & 1][2], da[g & 1].z, acc);
+                    acc = MFMA(dk4[g & 1][3], da[g & 1].w, acc);
+                    FENCE();
+                }
+            } else {
+                ldv<VEC>(tQ + vb[0][0], ea[0]);
+            }
+            STAMP(5);
+            if (seam) {                                // every wave is done with this K block: request the next one
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                issue_kblock(kb + 1);
+                load_vfrag(kb + 1);
+            }
+            // ---- dK^T[d, kv] += Q^T[d, q] dS[q, kv]; the dQ stores ride along, one per step
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (r + 1 < 16) ldv<VEC>(tQ + vb[((r + 1) >> 2) & 1][(r + 1) & 3] + T::vec_imm(r + 1), ea[(r + 1) & 1]);
+                if ((r & 3) == 0 && 8 * (r >> 2) < D) {
+                    const int g4 = r >> 2;
+                    const u32x4_t v = {__float_as_uint(acc[r] + dq_old[g4].x), __float_as_uint(acc[r + 1] + dq_old[g4].y),
+                                       __float_as_uint(acc[r + 2] + dq_old[g4].z), __float_as_uint(acc[r + 3] + dq_old[g4].w)};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrcDQw, dq_voff + 32 * g4, dq_tile, 0);
+                }
+                FENCE();
+#pragma unroll
+                for (int t = 0; t < DT; ++t) dK[t] = MFMA(ea[r & 1][t], dS[r], dK[t]);
+                FENCE();
+            }
+            in_flight = 4;
+            ++it;
+            STAMP(6);
+            STAMP(7);
+            FENCE();
+        }
+        if (SEAM_STORES == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // this block's dK and dV rows: lane = key; register r of the DT tiles together is VEC adjacent head dimensions
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d0 = VEC * (4 * half + (r & 3) + 8 * (r >> 2));
+            if (VEC * (8 * (r >> 2) + (r & 3)) < D) {
+                const bool ok = kvok && d0 < D;
+                const int offk = ok ? (int)((kvrow * p.dk_pitch + d0) * 4) : OOB, offv = ok ? (int)((kvrow * p.dv_pitch + d0) * 4) : OOB;
+                if (VEC == 4) {
+                    buf_store4(rsrcDK, offk, dK[0][r], dK[DT > 1 ? 1 : 0][r], dK[DT > 2 ? 2 : 0][r], dK[DT > 3 ? 3 : 0][r]);
+                    buf_store4(rsrcDV, offv, dV[0][r], dV[DT > 1 ? 1 : 0][r], dV[DT > 2 ? 2 : 0][r], dV[DT > 3 ? 3 : 0][r]);
+                } else {
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dK[t][r]), rsrcDK, ok ? offk + 4 * t : OOB, 0, 0);
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(dV[t][r]), rsrcDV, ok ? offv + 4 * t : OOB, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+}
+
+long long *g_attn_trace = nullptr;
+int g_attn_stagger = 1;
+
+// delta[b, h, s] = sum_d dO[b, s, h, d] * O[b, s, h, d]: half a wavefront (32 lanes x float4) per (b, s, h) row.
+__global__ void __launch_bounds__(256)
+mha_delta_kernel(const float *__restrict__ dctx, long dctx_pitch, const float *__restrict__ ctx, long ctx_pitch,
+                 float *__restrict__ delta, long batch, long seq, int heads, int dim) {
+    const long rows = batch * seq * heads;
+    const int sub = threadIdx.x & 31;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (row >= rows) return;
+    const long bs = row / heads;
+    const int h = (int)(row - bs * heads);
+    const float *pa = dctx + bs * dctx_pitch + (long)h * dim, *pb = ctx + bs * ctx_pitch + (long)h * dim;
+    float acc = 0.f;
+    for (int c0 = sub * 4; c0 < dim; c0 += 128) {
+        const float4 x = ld4(pa + c0), y = ld4(pb + c0);
+        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) {
+        const long s_ = bs % seq, b_ = bs / seq;
+        delta[(b_ * heads + h) * seq + s_] = acc;
+    }
+}
+
+template <int D>
+int launch_fwd(const MhaArgs &a, hipStream_t s) {
+    const int grid = a.batch * a.heads * a.q_tiles;
+    const bool mask = a.mask != nullptr, save = a.scores != nullptr;
+    if (mask && save) hipLaunchKernelGGL((mha_fwd_kernel<D, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (mask) hipLaunchKernelGGL((mha_fwd_kernel<D, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (save) hipLaunchKernelGGL((mha_fwd_kernel<D, false, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mha_fwd_kernel<D, false, false>), dim3(grid), dim3(256), 0, s, a);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+template <int D>
+int launch_bwd(const MhaArgs &a, hipStream_t s) {
+    const int grid = a.batch * a.heads;
+    const bool mask = a.mask != nullptr, saved = a.scores != nullptr;
+    if (mask && saved) hipLaunchKernelGGL((mha_bwd_kernel<D, true, true>), dim3(grid), dim3(256), 0, s, a);
+    else if (mask) hipLaunchKernelGGL((mha_bwd_kernel<D, true, false>), dim3(grid), dim3(256), 0, s, a);
+    else if (saved) hipLaunchKernelGGL((mha_bwd_kernel<D, false, true>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mha_bwd_kernel<D, false, false>), dim3(grid), dim3(256), 0, s, a);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+
+inline bool al16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
+
+int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
+    NPM_ARG(c != nullptr);
+    NPM_ARG(c->batch >= 0 && c->heads >= 1 && c->seq_q >= 0 && c->seq_kv >= 1);
+    const int d = c->head_dim;
+    if (!(d == 16 || d == 32 || d == 64 || d == 128))
+        return npm::fail(NPM_E_UNSUPPORTED, "npm_mha_core: head_dim %d is not one of 16, 32, 64, 128 (use the GEMM composition)", d);
+    NPM_ARG(c->scale > 0.f);
+    NPM_ARG(c->q && c->k && c->v && c->ctx && c->lse);
+    auto pitch_ok = [&](int64_t pitch) { return pitch >= (int64_t)c->heads * d && pitch % 4 == 0; };
+    NPM_ARG(pitch_ok(c->q_pitch) && pitch_ok(c->k_pitch) && pitch_ok(c->v_pitch) && pitch_ok(c->ctx_pitch));
+    NPM_ARG(al16(c->q) && al16(c->k) && al16(c->v) && al16(c->ctx));
+    auto span_ok = [&](int64_t rows, int64_t pitch) { return (rows + 128) * pitch * 4 < (1LL << 31); };   // per (batch) extent below 2^31 bytes
+    NPM_ARG(span_ok(c->seq_q, c->q_pitch) && span_ok(c->seq_kv, c->k_pitch) && span_ok(c->seq_kv, c->v_pitch) && span_ok(c->seq_q, c->ctx_pitch));
+    a = MhaArgs{};
+    a.q = c->q; a.k = c->k; a.v = c->v;
+    a.q_pitch = c->q_pitch; a.k_pitch = c->k_pitch; a.v_pitch = c->v_pitch;
+    a.ctx = c->ctx; a.ctx_pitch = c->ctx_pitch; a.lse = c->lse;
+    a.mask = c->mask; a.mask_sb = c->mask_stride_b; a.mask_sh = c->mask_stride_h; a.mask_sq = c->mask_stride_q;
+    a.scores = c->scores;
+    NPM_ARG(!c->scores || al16(c->scores));
+    a.batch = c->batch; a.heads = c->heads; a.seq_q = c->seq_q; a.seq_kv = c->seq_kv;
+    a.scale = c->scale;
+    a.q_tiles = (c->seq_q + 127) / 128;
+    a.trace = g_attn_trace;
+    a.stagger = g_attn_stagger;
+    if (backward) {
+        NPM_ARG(c->dctx && c->dq && c->dk && c->dv);
+        NPM_ARG(pitch_ok(c->dctx_pitch) && pitch_ok(c->dq_pitch) && pitch_ok(c->dk_pitch) && pitch_ok(c->dv_pitch));
+        NPM_ARG(al16(c->dctx) && al16(c->dq) && al16(c->dk) && al16(c->dv));
+        NPM_ARG(span_ok(c->seq_q, c->dctx_pitch) && span_ok(c->seq_q, c->dq_pitch) && span_ok(c->seq_kv, c->dk_pitch) && span_ok(c->seq_kv, c->dv_pitch));
+        a.dctx = c->dctx; a.dctx_pitch = c->dctx_pitch;
+        a.dq = c->dq; a.dk = c->dk; a.dv = c->dv;
+        a.dq_pitch = c->dq_pitch; a.dk_pitch = c->dk_pitch; a.dv_pitch = c->dv_pitch;
+    }
+    return NPM_OK;
+}
+
+}  // namespace
+
+extern "C" int npm_debug_attn_trace(long long *buf) { g_attn_trace = buf; return NPM_OK; }
+extern "C" int npm_attn_set_stagger(int units) { g_attn_stagger = units < 0 ? 0 : units; return NPM_OK; }
+
+extern "C" int npm_mha_core_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
+
+extern "C" int npm_mha_core_fwd(const npm_mha_core *c) {
+    NPM_REQUIRE_INIT();
+    MhaArgs a;
+    int rc = fill_args(c, false, a);
+    if (rc) return rc;
+    if ((long)a.batch * a.heads * a.q_tiles == 0) return NPM_OK;
+    NPM_ARG((long)a.batch * a.heads * a.q_tiles < (1L << 31));
+    hipStream_t s = npm::ctx().stream;
+    switch (c->head_dim) {
+        case 16: return launch_fwd<16>(a, s);
+        case 32: return launch_fwd<32>(a, s);
+        case 64: return launch_fwd<64>(a, s);
+        default: return launch_fwd<128>(a, s);
+    }
+}
+
+extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
+    NPM_REQUIRE_INIT();
+    MhaArgs a;
+    int rc = fill_args(c, true, a);
+    if (rc) return rc;
+    if ((long)a.batch * a.heads == 0 || a.seq_q == 0) return NPM_OK;
+    hipStream_t s = npm::ctx().stream;
+    npm::Scratch ws;                                   // stream-ordered pool: safe to release when this call returns
+    const long rows = (long)a.batch * a.seq_q * a.heads;
+    rc = ws.alloc(sizeof(float) * (size_t)rows);
+    if (rc) return rc;
+    a.delta = (float *)ws.ptr;
+    NPM_ARG((rows * 32 + 255) / 256 < (1L << 31));
+    hipLaunchKernelGGL(mha_delta_kernel, dim3((int)((rows * 32 + 255) / 256)), dim3(256), 0, s, a.dctx, a.dctx_pitch,
+                       (const float *)a.ctx, a.ctx_pitch, a.delta, (long)a.batch, (long)a.seq_q, a.heads, c->head_dim);
+    NPM_CHECK_LAUNCH();
+    switch (c->head_dim) {
+        case 16: return launch_bwd<16>(a, s);
+        case 32: return launch_bwd<32>(a, s);
+        case 64: return launch_bwd<64>(a, s);
+        default: return launch_bwd<128>(a, s);
+    }
+}

@@ -406,6 +406,7 @@ extern "C" int npm_conv_set_dma(int on);
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
 extern "C" int npm_conv_set_wave_prio(int bits);
 extern "C" int npm_conv_set_math(int mode);
+extern "C" int npm_attn_set_stagger(int units);
 
 extern "C" int npm_set_math(int mode) { return npm_set_tuning(NPM_TUNE_GEMM_MATH, mode); }
 extern "C" int npm_get_math(void) { return g_math; }
@@ -427,6 +428,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_WAVE_PRIO: g_wave_prio = value; return npm_conv_set_wave_prio(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
+        case NPM_TUNE_ATTN_STAGGER: return npm_attn_set_stagger(value);
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }
 }

@@ -395,6 +395,11 @@ FUSE_COLSUM = os.environ.get('NPM_FUSE_COLSUM', '1') != '0'      # A/B switches 
 FUSE_SOFTMAX_BWD = os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
 FUSE_BSUM = os.environ.get('NPM_FUSE_BSUM', '1') != '0'          # bias gradient inside the weight-gradient GEMM
 PACK_QKV = os.environ.get('NPM_PACK_QKV', '1') != '0'
+ATTN_CORE = os.environ.get('NPM_ATTN_CORE', '1') != '0'            # fused attention core (npm_mha_core_*) where it applies
+# The forward keeps the raw scores for the backward by default: on this chip the fp32 matrix rate is the scarce
+# resource (a 32 x 32 score tile costs 64 MFMAs to recompute, 16 loads to read back; measured 5.25 vs 5.86 ms for the
+# C4 backward); NPM_ATTN_SAVE_SCORES=0 is the memory-lean mode (log-sum-exp only, 2.1 GB less at C4 / C5).
+ATTN_SAVE_SCORES = os.environ.get('NPM_ATTN_SAVE_SCORES', '1') != '0'
 
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its
@@ -617,3 +622,82 @@ def layernorm_bwd(dz: DeviceArray, x: DeviceArray, mean: DeviceArray, rstd: Devi
                                             None if residual is None else residual.ptr, rows, d,
                                             dx.ptr, dgamma.ptr, dbeta.ptr), 'npm_layernorm_bwd')
     return dx
+
+
+# ---- fused attention core ----------------------------------------------------------------------------
+def mha_core_supported(head_dim: int, value_dim: Optional[int] = None, *, any_math: bool = False) -> bool:
+    """Whether the fused attention kernels take this head size.  They run the exact-fp32 MFMA only, so under a
+    split-bf16 math mode the layers keep composing attention from ``gemm`` (which honours the mode) unless
+    ``any_math`` is set (masked attention exists only in the fused kernels)."""
+    if not ATTN_CORE or (value_dim is not None and value_dim != head_dim):
+        return False
+    if not any_math and _C.current_math() != 'f32':
+        return False
+    return bool(_C.lib().npm_mha_core_supported(int(head_dim)))
+
+
+class AttnMask:
+    """A boolean attention mask on the device: bytes plus (batch, head, query) strides; broadcast axes have
+    stride 0.  ``np.where(mask, scaled, -inf)`` of reference layers/attentions.py:105-107."""
+
+    def __init__(self, mask, b: int, h: int, sq: int, skv: int):
+        host = np.asarray(mask).astype(bool)
+        while host.ndim < 4:
+            host = host[None]
+        if host.ndim != 4 or any(have not in (1, want) for have, want in zip(host.shape, (b, h, sq, skv))):
+            raise AssertionError(f'mask shape {np.shape(mask)} does not broadcast to {(b, h, sq, skv)}')
+        if host.shape[3] != skv:
+            host = np.broadcast_to(host, host.shape[:3] + (skv,))
+        host = np.ascontiguousarray(host).astype(np.uint8)
+        self.host = host.astype(bool)
+        self.buf = bytes_from_host(host)
+        nb, nh, nq, _ = host.shape
+        self.strides = (0 if nb == 1 else nh * nq * skv, 0 if nh == 1 else nq * skv, 0 if nq == 1 else skv)
+
+    def full(self, b, h, sq, skv) -> np.ndarray:
+        return np.broadcast_to(self.host, (b, h, sq, skv))
+
+
+def _core_desc(q: Mat, k: Mat, v: Mat, ctx: Mat, lse: DeviceArray, dims, scale: float,
+               mask: Optional[AttnMask], scores: Optional[DeviceArray]):
+    b, h, sq, skv, d = (int(x) for x in dims)
+    c = _C.npm_mha_core()
+    c.batch, c.heads, c.seq_q, c.seq_kv, c.head_dim = b, h, sq, skv, d
+    c.scale = float(scale)
+    c.q, c.q_pitch, c.k, c.k_pitch, c.v, c.v_pitch = q.ptr, q.ld, k.ptr, k.ld, v.ptr, v.ld
+    c.ctx, c.ctx_pitch, c.lse = ctx.ptr, ctx.ld, lse.ptr
+    if mask is not None:
+        c.mask = mask.buf.ptr
+        c.mask_stride_b, c.mask_stride_h, c.mask_stride_q = mask.strides
+    if scores is not None:
+        c.scores = scores.ptr
+    return c
+
+
+def mha_core_fwd(q: Mat, k: Mat, v: Mat, dims, scale: float, mask: Optional[AttnMask] = None,
+                 save_scores: bool = False):
+    """ctx[b, i, h, :] = softmax_j(scale q_i . k_j [masked]) v_j in one kernel (include/npm_hip.h npm_mha_core_fwd).
+    ``q``/``k``/``v``: (array, row pitch) of [B, S, H, D] operands.  Returns (ctx [B, Sq, H, D], lse [B, H, Sq],
+    scores or None)."""
+    b, h, sq, skv, d = dims
+    ctx, lse = empty([b, sq, h, d]), empty([b, h, sq])
+    scores = empty([b, h, sq, skv]) if save_scores else None
+    c = _core_desc(q, k, v, Mat(ctx, h * d), lse, dims, scale, mask, scores)
+    nbytes = 4.0 * b * h * d * (2 * sq + 2 * skv) + (4.0 * b * h * sq * skv if save_scores else 0.0)
+    with _timed('mha_core_fwd', flops=4.0 * b * h * sq * skv * d, nbytes=nbytes):
+        _C.check(_C.lib().npm_mha_core_fwd(C.byref(c)), 'npm_mha_core_fwd')
+    return ctx, lse, scores
+
+
+def mha_core_bwd(q: Mat, k: Mat, v: Mat, ctx: DeviceArray, lse: DeviceArray, dctx: DeviceArray,
+                 dq: Mat, dk: Mat, dv: Mat, dims, scale: float, mask: Optional[AttnMask] = None,
+                 scores: Optional[DeviceArray] = None) -> None:
+    """dq, dk, dv of the attention core from q, k, v, the forward's ctx and lse, and dctx (npm_mha_core_bwd).
+    Algorithmic work: the four products dP, dV, dK, dQ (the recomputed q.k is the kernel's own business)."""
+    b, h, sq, skv, d = dims
+    c = _core_desc(q, k, v, Mat(ctx, h * d), lse, dims, scale, mask, scores)
+    c.dctx, c.dctx_pitch = dctx.ptr, h * d
+    c.dq, c.dq_pitch, c.dk, c.dk_pitch, c.dv, c.dv_pitch = dq.ptr, dq.ld, dk.ptr, dk.ld, dv.ptr, dv.ld
+    nbytes = 4.0 * b * h * d * (4 * sq + 4 * skv) + (4.0 * b * h * sq * skv if scores is not None else 0.0)
+    with _timed('mha_core_bwd', flops=8.0 * b * h * sq * skv * d, nbytes=nbytes):
+        _C.check(_C.lib().npm_mha_core_bwd(C.byref(c)), 'npm_mha_core_bwd')

@@ -13,6 +13,18 @@ materialised:
   (the reference's own cache is head-major [B, H, Sq, Dv]; this one is private state);
 * softmax forward/backward with the 1/sqrt(Dk) scaling fused (attentions.py:104,150-155).
 
+Where the head size allows (Dk == Dv in {16, 32, 64, 128}, exact-fp32 math) the score / softmax / context chain and
+its gradient run as ONE kernel each (``npm_mha_core_fwd`` / ``npm_mha_core_bwd``, csrc/npm_attn.hip): the
+[B, H, Sq, Skv] probabilities are never stored, only a log-sum-exp per query row.  The GEMM composition above stays
+as the path for other head sizes and for the split-bf16 math modes.
+
+Masks.  The reference tests ``if mask:`` (attentions.py:84,106), which raises ValueError for any array of more than
+one element, and its backward raises NotImplementedError (attentions.py:152-153): masked attention is unreachable
+there.  This layer implements the evident intent instead: ``mask`` is a boolean array broadcastable to
+[B, H, Sq, Skv]; excluded positions get ``-inf`` before the softmax (``np.where(mask, scaled, -inf)``) and
+probability exactly 0, in forward and backward; a query row with no position left yields NaN, as that ``np.where``
+followed by the reference's softmax would.
+
 Parameter layouts are the reference's: wq/wk [H, Dk, H*Dk], wv [H, Dv, H*Dv], wo [H*Dk, H, Dv],
 bq/bk [H, Dk], bv [H, Dv], bo [H*Dk] (attentions.py:46-65), drawn in that order.
 """
@@ -21,6 +33,8 @@ from __future__ import annotations
 
 import math
 from typing import Optional
+
+import numpy as np
 
 from np_modeling_amd import device as D
 from np_modeling_amd import parallel
@@ -93,14 +107,12 @@ class MultiHeadAttention(layer.StatefulLayer):
 
     # -- forward -------------------------------------------------------------------------
     def forward(self, query, key=None, value=None, mask=None):
-        if mask is not None and bool(mask):     # ndarray masks raise ValueError here, as attentions.py:84
-            raise NotImplementedError('attention masks are not supported (reference: attentions.py:152-153)')
         query = D.as_device(query)
         key = query if key is None else D.as_device(key)
         value = key if value is None else D.as_device(value)
-        return self._forward_impl(query, key, value)
+        return self._forward_impl(query, key, value, mask=mask)
 
-    def _forward_impl(self, query, key, value, residual: Optional[D.DeviceArray] = None):
+    def _forward_impl(self, query, key, value, residual: Optional[D.DeviceArray] = None, mask=None):
         h, dk, dv = self._num_heads, self._key_dim, self._value_dim
         b, sq, f = query.shape
         skv = key.shape[1]
@@ -108,7 +120,14 @@ class MultiHeadAttention(layer.StatefulLayer):
         assert f == h * dk and key.shape == (b, skv, f) and value.shape[:2] == (b, skv) and fv == h * dv
         wq, wk, wv, wo = (self._param(p) for p in ('_wq', '_wk', '_wv', '_wo'))
         bq, bk, bv, bo = (self._param(p) for p in ('_bq', '_bk', '_bv', '_bo'))
-        self._query, self._key, self._value, self._mask = query, key, value, None
+        self._query, self._key, self._value = query, key, value
+        if mask is not None and np.ndim(mask) == 0 and not mask:       # `if mask:` false (attentions.py:84,106)
+            mask = None
+        self._mask = None if mask is None else D.AttnMask(mask, b, h, sq, skv)
+        core = D.mha_core_supported(dk, dv, any_math=self._mask is not None)
+        if self._mask is not None and not core:
+            raise NotImplementedError('masked attention needs head sizes Dk == Dv in {16, 32, 64, 128} (fused kernels)')
+        self._core = core
 
         # in-projections: [rows, F] x w[H*D, F]^T + b.  q/k/v are [B, S, H, D] head slices addressed through
         # (array, element offset, row pitch): separate tensors, or thirds of one packed [B, S, 3, H, D].
@@ -132,19 +151,25 @@ class MultiHeadAttention(layer.StatefulLayer):
         pq, pk, pv = pitch or h * dk, pitch or h * dk, pitch or h * dv       # row pitches of q, k, v
         self._pitches = (pq, pk, pv)
 
-        # attention[b, h] = q_h k_h^T ; scores = softmax(attention / sqrt(dk))
-        scores = D.empty([b, h, sq, skv])
-        D.gemm(sq, skv, dk, Mat(q, pq, sq * pq, dk), Mat(k, pk, skv * pk, dk),
-               Mat(scores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))
         self._scale = 1.0 / math.sqrt(dk)
-        D.softmax_fwd(scores, self._scale, out=scores)
-        self._softmax._y = scores
-        self._attention_scores = scores
-
-        # context[b, :, h, :] = scores[b, h] v_h      -> [B, Sq, H, Dv]
-        ctx = D.empty([b, sq, h, dv])
-        D.gemm(sq, dv, skv, Mat(scores, skv, h * sq * skv, sq * skv), Mat(v, pv, skv * pv, dv),
-               Mat(ctx, h * dv, sq * h * dv, dv), batch=(b, h))
+        if core:
+            # scores, softmax and context in one kernel; what the backward needs is the log-sum-exp per row
+            ctx, self._lse, self._raw_scores = D.mha_core_fwd(
+                Mat(q, pq), Mat(k, pk), Mat(v, pv), (b, h, sq, skv, dk), self._scale, self._mask,
+                save_scores=D.ATTN_SAVE_SCORES)
+            self._softmax._y = self._attention_scores = None
+        else:
+            # attention[b, h] = q_h k_h^T ; scores = softmax(attention / sqrt(dk))
+            scores = D.empty([b, h, sq, skv])
+            D.gemm(sq, skv, dk, Mat(q, pq, sq * pq, dk), Mat(k, pk, skv * pk, dk),
+                   Mat(scores, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))
+            D.softmax_fwd(scores, self._scale, out=scores)
+            self._softmax._y = scores
+            self._attention_scores = scores
+            # context[b, :, h, :] = scores[b, h] v_h      -> [B, Sq, H, Dv]
+            ctx = D.empty([b, sq, h, dv])
+            D.gemm(sq, dv, skv, Mat(scores, skv, h * sq * skv, sq * skv), Mat(v, pv, skv * pv, dv),
+                   Mat(ctx, h * dv, sq * h * dv, dv), batch=(b, h))
         self._context = ctx
 
         # output projection: [B*Sq, H*Dv] x wo[F, H*Dv]^T + bo (+ skip connection)
@@ -163,8 +188,6 @@ class MultiHeadAttention(layer.StatefulLayer):
         """Returns (dquery, dkey, dvalue) (attentions.py:199), or -- for a composite that feeds
         one tensor as query, key and value -- their sum (+ residual) accumulated in the GEMM
         epilogues when ``sum_inputs`` is set (reference layers/transformer.py:84-85)."""
-        if self._mask:
-            raise NotImplementedError
         h, dk, dv = self._num_heads, self._key_dim, self._value_dim
         query, key, value = self._query, self._key, self._value
         q, k, v, scores, ctx = self._q, self._k, self._v, self._attention_scores, self._context
@@ -181,23 +204,8 @@ class MultiHeadAttention(layer.StatefulLayer):
         dctx = D.empty([b, sq, h, dv])
         D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))                    # dy wo
 
-        # softmax @ V (attentions.py:146-148)
         packed = self._packed
         pq, pk, pv = self._pitches
-        # dP = dctx_h v_h^T followed by the softmax backward and the 1/sqrt(dk) of attentions.py:150-155.
-        # The row term sum_j dP_ij P_ij equals dctx_i . ctx_i (ctx = P v), so it is one cheap row-dot and the
-        # rest, datt = scale * P * (dP - row term), is elementwise: it rides the epilogue of the dP GEMM
-        # and dP itself never goes to memory.
-        datt = D.empty([b, h, sq, skv])
-        if D.FUSE_SOFTMAX_BWD:
-            delta = D.attn_rowdot(dctx, ctx)
-            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
-                   Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h), alpha=self._scale,
-                   softmax_bwd=(Mat(scores, skv), delta))
-        else:
-            D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
-                   Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))            # dctx_h v_h^T
-            D.softmax_bwd(scores, datt, self._scale, out=datt)
         # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): taken from the dq/dk/dv
         # tiles of the in-projection weight-gradient GEMMs below
         if packed:      # gradients of the packed parameters and of q/k/v live in packed buffers too
@@ -212,14 +220,33 @@ class MultiHeadAttention(layer.StatefulLayer):
             dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
             dq, dk_, dv_ = D.empty([b, sq, h, dk]), D.empty([b, skv, h, dk]), D.empty([b, skv, h, dv])
             gq, gk, gv = h * dk, h * dk, h * dv
-        D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
-               Mat(dv_, gv, skv * gv, dv), trans_a=True, batch=(b, h))                            # P_h^T dctx_h
-
-        # Q K^T (attentions.py:161-162)
-        D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, pk, skv * pk, dk),
-               Mat(dq, gq, sq * gq, dk), batch=(b, h))                                            # datt_h k_h
-        D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, pq, sq * pq, dk),
-               Mat(dk_, gk, skv * gk, dk), trans_a=True, batch=(b, h))                            # datt_h^T q_h
+        if self._core:
+            # attentions.py:146-162 in one kernel: P is recomputed from the saved log-sum-exp, tile by tile
+            D.mha_core_bwd(Mat(q, pq), Mat(k, pk), Mat(v, pv), ctx, self._lse, dctx, Mat(dq, gq), Mat(dk_, gk),
+                           Mat(dv_, gv), (b, h, sq, skv, dk), self._scale, self._mask, self._raw_scores)
+        else:
+            # softmax @ V (attentions.py:146-148)
+            # dP = dctx_h v_h^T followed by the softmax backward and the 1/sqrt(dk) of attentions.py:150-155.
+            # The row term sum_j dP_ij P_ij equals dctx_i . ctx_i (ctx = P v), so it is one cheap row-dot and the
+            # rest, datt = scale * P * (dP - row term), is elementwise: it rides the epilogue of the dP GEMM
+            # and dP itself never goes to memory.
+            datt = D.empty([b, h, sq, skv])
+            if D.FUSE_SOFTMAX_BWD:
+                delta = D.attn_rowdot(dctx, ctx)
+                D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
+                       Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h), alpha=self._scale,
+                       softmax_bwd=(Mat(scores, skv), delta))
+            else:
+                D.gemm(sq, skv, dv, Mat(dctx, h * dv, sq * h * dv, dv), Mat(v, pv, skv * pv, dv),
+                       Mat(datt, skv, h * sq * skv, sq * skv), trans_b=True, batch=(b, h))        # dctx_h v_h^T
+                D.softmax_bwd(scores, datt, self._scale, out=datt)
+            D.gemm(skv, dv, sq, Mat(scores, skv, h * sq * skv, sq * skv), Mat(dctx, h * dv, sq * h * dv, dv),
+                   Mat(dv_, gv, skv * gv, dv), trans_a=True, batch=(b, h))                        # P_h^T dctx_h
+            # Q K^T (attentions.py:161-162)
+            D.gemm(sq, dk, skv, Mat(datt, skv, h * sq * skv, sq * skv), Mat(k, pk, skv * pk, dk),
+                   Mat(dq, gq, sq * gq, dk), batch=(b, h))                                        # datt_h k_h
+            D.gemm(skv, dk, sq, Mat(datt, skv, h * sq * skv, sq * skv), Mat(q, pq, sq * pq, dk),
+                   Mat(dk_, gk, skv * gk, dk), trans_a=True, batch=(b, h))                        # datt_h^T q_h
 
         # in-projections (attentions.py:167-188): dw = dproj^T x ; dx = dproj w
         if packed:

@@ -235,7 +235,7 @@ def mha_init(num_heads: int, features: int, value_features: Optional[int] = None
 
 
 def mha_fwd(p: Dict[str, Array], query: Array, key: Optional[Array] = None,
-            value: Optional[Array] = None, verbatim: bool = False):
+            value: Optional[Array] = None, verbatim: bool = False, mask: Optional[Array] = None):
     """Projections, scaled QK^T, softmax, PV, output projection (attentions.py:88-120).
 
     verbatim uses the reference's einsum strings; otherwise the same contractions are
@@ -258,6 +258,8 @@ def mha_fwd(p: Dict[str, Array], query: Array, key: Optional[Array] = None,
         v = (value.reshape(b * skv, -1) @ p['wv'].reshape(h * dv, -1).T).reshape(b, skv, h, dv) + p['bv']
         att = np.matmul(q.transpose(0, 2, 1, 3), k.transpose(0, 2, 3, 1))
     scaled = (1.0 / np.sqrt(dk)) * att            # np.float64 scalar -> fp64 under NumPy 2
+    if mask is not None:                          # attentions.py:105-107 as written (see attention_core_fwd)
+        scaled = np.where(mask, scaled, float('-inf'))
     scores = softmax_fwd(scaled)                  # [b, h, sq, skv]
     if verbatim:
         values = np.einsum('...abc,...cad->...abd', scores, v)
@@ -324,6 +326,70 @@ def mha_bwd(p: Dict[str, Array], cache: Dict[str, Array], dy: Array, verbatim: b
     g['bk'] = dk_.sum(axis=(0, 1))
     g['bv'] = dv.sum(axis=(0, 1))
     return (dquery, dkey, dvalue), g
+
+
+# --------------------------------------------------------------------------- #
+# Attention core: scores -> softmax -> context and its gradient, on [B, S, H, D] q/k/v
+# (the middle of reference layers/attentions.py: 103-112 forward, 146-162 backward)
+# --------------------------------------------------------------------------- #
+def attention_core_fwd(q: Array, k: Array, v: Array, scale: float, mask: Optional[Array] = None):
+    """q [B,Sq,H,D], k/v [B,Skv,H,D] -> (ctx [B,Sq,H,Dv], lse [B,H,Sq], probabilities [B,H,Sq,Skv]).
+
+    attentions.py:103-104 (QK^T einsum, 1/sqrt(Dk)), :105-107 (``np.where(mask, scaled, -inf)`` -- the line is
+    unreachable for real masks in the reference because of the ``if mask:`` in front of it; restated as written),
+    :108 (max-shifted softmax), :112 (PV).  lse = log sum_j exp(scaled_ij), what a fused kernel keeps instead of
+    the probabilities."""
+    scaled = scale * np.einsum('bqhd,bkhd->bhqk', q, k)
+    if mask is not None:
+        scaled = np.where(mask, scaled, -np.inf)
+    top = scaled.max(axis=-1, keepdims=True)
+    shifted = np.exp(scaled - top)
+    total = shifted.sum(axis=-1, keepdims=True)
+    probs = shifted / total
+    ctx = np.einsum('bhqk,bkhd->bqhd', probs, v)
+    return ctx, (top + np.log(total))[..., 0], probs
+
+
+def attention_core_bwd(q: Array, k: Array, v: Array, probs: Array, dctx: Array, scale: float):
+    """(dq, dk, dv) from the probabilities and dctx [B,Sq,H,Dv] (attentions.py:146-162; masked positions carry
+    probability 0 and therefore no gradient -- the reference raises NotImplementedError there)."""
+    dprobs = np.einsum('bqhd,bkhd->bhqk', dctx, v)
+    dv = np.einsum('bhqk,bqhd->bkhd', probs, dctx)
+    dscaled = softmax_bwd(probs, dprobs) * scale
+    dq = np.einsum('bhqk,bkhd->bqhd', dscaled, k)
+    dk = np.einsum('bhqk,bqhd->bkhd', dscaled, q)
+    return dq, dk, dv
+
+
+def attention_core_fwd_blockwise(q: Array, k: Array, v: Array, scale: float, q_block: int = 32, kv_block: int = 32):
+    """The blockwise online-softmax forward the reference derives in layers/attentions_test.py:194-246 (running
+    maximum m_i, running sum l_i, accumulator rescaled by l_i / l_i_new), restated for [B, S, H, D] operands of any
+    length; returns (ctx, lse).  It is the algorithm of csrc/npm_attn.hip's forward kernel, checked here against
+    the one-shot form above."""
+    b, sq, h, d = q.shape
+    skv = k.shape[1]
+    ctx = np.zeros([b, sq, h, v.shape[3]])
+    lse = np.zeros([b, h, sq])
+    for q0 in range(0, sq, q_block):
+        tq = q[:, q0:q0 + q_block]
+        nq = tq.shape[1]
+        m_i = np.full([b, h, nq], -np.inf)
+        l_i = np.zeros([b, h, nq])
+        acc = np.zeros([b, nq, h, v.shape[3]])
+        for k0 in range(0, skv, kv_block):
+            tk, tv = k[:, k0:k0 + kv_block], v[:, k0:k0 + kv_block]
+            p_ij = scale * np.einsum('bqhd,bkhd->bhqk', tq, tk)
+            m_new = np.maximum(p_ij.max(axis=3), m_i)
+            l_i = l_i * np.exp(m_i - m_new)
+            p_ij = np.exp(p_ij - m_new[..., None])
+            l_new = p_ij.sum(axis=3) + l_i
+            p_ij = p_ij / l_new[..., None]
+            acc = acc * np.transpose((l_i / l_new)[..., None], [0, 2, 1, 3])
+            m_i, l_i = m_new, l_new
+            acc = acc + np.einsum('bhqk,bkhd->bqhd', p_ij, tv)
+        ctx[:, q0:q0 + q_block] = acc
+        lse[:, :, q0:q0 + q_block] = m_i + np.log(l_i)
+    return ctx, lse
 
 
 # --------------------------------------------------------------------------- #

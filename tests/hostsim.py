@@ -230,6 +230,62 @@ class HostSim:
         _vec(dbeta, d)[:] = db
         return 0
 
+    # ---- fused attention core ------------------------------------------------------------------------
+    def npm_mha_core_supported(self, head_dim):
+        return int(head_dim in (16, 32, 64, 128))
+
+    @staticmethod
+    def _heads(ptr, pitch, b, s, h, d):
+        """[B, S, H, D] view of a pitched operand."""
+        flat = _vec(ptr, ((b * s - 1) * pitch + h * d) if b * s else 0)
+        return np.lib.stride_tricks.as_strided(flat, shape=(b, s, h, d), strides=(4 * s * pitch, 4 * pitch, 4 * d, 4))
+
+    def _core_mask(self, c):
+        if not c.mask:
+            return None
+        b, h, sq, skv = c.batch, c.heads, c.seq_q, c.seq_kv
+        extent = (b - 1) * c.mask_stride_b + (h - 1) * c.mask_stride_h + (sq - 1) * c.mask_stride_q + skv
+        raw = np.ctypeslib.as_array((C.c_ubyte * int(extent)).from_address(_addr(c.mask)))
+        return np.lib.stride_tricks.as_strided(raw, shape=(b, h, sq, skv),
+                                               strides=(c.mask_stride_b, c.mask_stride_h, c.mask_stride_q, 1)) != 0
+
+    def npm_mha_core_fwd(self, cref):
+        c = _deref(cref)
+        self.calls.append('npm_mha_core_fwd')
+        if c.head_dim not in (16, 32, 64, 128):
+            return 10003
+        b, h, sq, skv, d = c.batch, c.heads, c.seq_q, c.seq_kv, c.head_dim
+        q, k, v = (self._heads(ptr, pitch, b, s, h, d).astype(np.float64)
+                   for ptr, pitch, s in ((c.q, c.q_pitch, sq), (c.k, c.k_pitch, skv), (c.v, c.v_pitch, skv)))
+        mask = self._core_mask(c)
+        with np.errstate(invalid='ignore'):
+            ctx, lse, _ = O.attention_core_fwd(q, k, v, float(c.scale), mask)
+        self._heads(c.ctx, c.ctx_pitch, b, sq, h, d)[:] = ctx
+        _vec(c.lse, b * h * sq)[:] = lse.ravel()
+        if c.scores:
+            raw = np.einsum('bqhd,bkhd->bhqk', q, k)
+            _vec(c.scores, b * h * sq * skv)[:] = (raw if mask is None else np.where(mask, raw, -np.inf)).ravel()
+        return 0
+
+    def npm_mha_core_bwd(self, cref):
+        c = _deref(cref)
+        self.calls.append('npm_mha_core_bwd')
+        b, h, sq, skv, d = c.batch, c.heads, c.seq_q, c.seq_kv, c.head_dim
+        q, k, v = (self._heads(ptr, pitch, b, s, h, d).astype(np.float64)
+                   for ptr, pitch, s in ((c.q, c.q_pitch, sq), (c.k, c.k_pitch, skv), (c.v, c.v_pitch, skv)))
+        dctx = self._heads(c.dctx, c.dctx_pitch, b, sq, h, d).astype(np.float64)
+        lse = _vec(c.lse, b * h * sq).astype(np.float64).reshape(b, h, sq)
+        scaled = float(c.scale) * np.einsum('bqhd,bkhd->bhqk', q, k)
+        mask = self._core_mask(c)
+        if mask is not None:
+            scaled = np.where(mask, scaled, -np.inf)
+        probs = np.exp(scaled - lse[..., None])             # from the saved log-sum-exp, as the kernel does
+        dq, dk, dv = O.attention_core_bwd(q, k, v, probs, dctx, float(c.scale))
+        self._heads(c.dq, c.dq_pitch, b, sq, h, d)[:] = dq
+        self._heads(c.dk, c.dk_pitch, b, skv, h, d)[:] = dk
+        self._heads(c.dv, c.dv_pitch, b, skv, h, d)[:] = dv
+        return 0
+
     # ---- conv -----------------------------------------------------------------------------------
     def npm_conv2d_fwd(self, cref):
         c = _deref(cref)

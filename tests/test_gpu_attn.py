@@ -1,0 +1,280 @@
+"""GPU: the fused attention core (csrc/npm_attn.hip: npm_mha_core_fwd / npm_mha_core_bwd) through the C ABI against
+the oracle's restatement of reference layers/attentions.py:103-112,146-162, and through the layer (masks, the
+GEMM composition as a second opinion)."""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import assert_close as _assert_close
+from oracle import np_oracle as O
+
+
+def assert_close(got, ref, tol=1e-5, what=''):
+    """conftest's metric with a floor on the scale: operands here are O(1), and a single-key problem has dq = dk = 0
+    exactly (P = 1, dS = P (dP - delta) = 0), which fp32 returns as rounding noise of that magnitude times 1e-7."""
+    ref = np.asarray(ref, dtype=np.float64)
+    if ref.size and np.abs(ref).max() < 1.0:
+        np.testing.assert_allclose(np.asarray(got, dtype=np.float64), ref, rtol=tol, atol=tol, err_msg=what)
+    else:
+        _assert_close(got, ref, tol=tol, what=what)
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def npm():
+    import np_modeling_amd
+    return np_modeling_amd
+
+
+def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=False, lse_ctx=None):
+    """q [B,Sq,H,D], k/v [B,Skv,H,D] host arrays -> dict of host results from the C ABI.  ``packed``: q, k, v
+    live in one [B, S, 3, H, D] buffer (row pitch 3 H D), like the layer's packed projection."""
+    from np_modeling_amd import _C, device as D
+    lib = _C.lib()
+    b, sq, h, d = q.shape
+    skv = k.shape[1]
+    guard = 64
+    if packed:
+        assert sq == skv
+        buf = np.stack([q, k, v], axis=2)                       # [B, S, 3, H, D]
+        dev = D.from_host(buf)
+        qd, kd, vd = dev, dev.flat_view(h * d, [dev.size - h * d]), dev.flat_view(2 * h * d, [dev.size - 2 * h * d])
+        pitch = 3 * h * d
+        pitches = (pitch, pitch, pitch)
+    else:
+        qd, kd, vd = D.from_host(q), D.from_host(k), D.from_host(v)
+        pitches = (h * d, h * d, h * d)
+    ctx = D.full([b * sq * h * d + guard], 777.0)               # guard region behind every output
+    lse = D.full([b * h * sq + guard], 777.0)
+    c = _C.npm_mha_core()
+    c.batch, c.heads, c.seq_q, c.seq_kv, c.head_dim, c.scale = b, h, sq, skv, d, scale
+    c.q, c.k, c.v = qd.ptr, kd.ptr, vd.ptr
+    c.q_pitch, c.k_pitch, c.v_pitch = pitches
+    c.ctx, c.ctx_pitch, c.lse = ctx.ptr, h * d, lse.ptr
+    mask_dev = None
+    if mask is not None:
+        mask_dev = D.AttnMask(mask, b, h, sq, skv)
+        c.mask = mask_dev.buf.ptr
+        c.mask_stride_b, c.mask_stride_h, c.mask_stride_q = mask_dev.strides
+    scores = None
+    if save:
+        scores = D.full([b * h * sq * skv + guard], 777.0)
+        c.scores = scores.ptr
+    _C.check(lib.npm_mha_core_fwd(C.byref(c)), 'npm_mha_core_fwd')
+    out = {'ctx': ctx.numpy(), 'lse': lse.numpy()}
+    for key, n in (('ctx', b * sq * h * d), ('lse', b * h * sq)):
+        np.testing.assert_array_equal(out[key][n:], 777.0)      # nothing written past the end
+        out[key] = out[key][:n]
+    out['ctx'] = out['ctx'].reshape(b, sq, h, d)
+    out['lse'] = out['lse'].reshape(b, h, sq)
+    if save:
+        raw = scores.numpy()
+        np.testing.assert_array_equal(raw[b * h * sq * skv:], 777.0)
+        out['scores'] = raw[:b * h * sq * skv].reshape(b, h, sq, skv)
+    if dctx is not None:
+        if lse_ctx is not None:                                 # the oracle's forward results: isolates the backward
+            ctx.flat_view(0, [b, sq, h, d]).set(lse_ctx[1])
+            lse.flat_view(0, [b, h, sq]).set(lse_ctx[0])
+        grads = {}
+        if packed:
+            gbuf = D.full([b * sq * 3 * h * d + guard], 777.0)
+            views = [gbuf.flat_view(i * h * d, [gbuf.size - i * h * d]) for i in range(3)]
+            gp = (3 * h * d,) * 3
+        else:
+            views = [D.full([b * s * h * d + guard], 777.0) for s in (sq, skv, skv)]
+            gp = (h * d,) * 3
+        dctx_d = D.from_host(dctx)
+        c.dctx, c.dctx_pitch = dctx_d.ptr, h * d
+        c.dq, c.dk, c.dv = (x.ptr for x in views)
+        c.dq_pitch, c.dk_pitch, c.dv_pitch = gp
+        _C.check(lib.npm_mha_core_bwd(C.byref(c)), 'npm_mha_core_bwd')
+        if packed:
+            raw = gbuf.numpy()
+            np.testing.assert_array_equal(raw[b * sq * 3 * h * d:], 777.0)
+            g = raw[:b * sq * 3 * h * d].reshape(b, sq, 3, h, d)
+            grads = {'dq': g[:, :, 0], 'dk': g[:, :, 1], 'dv': g[:, :, 2]}
+        else:
+            for name, x, s in zip(('dq', 'dk', 'dv'), views, (sq, skv, skv)):
+                raw = x.numpy()
+                np.testing.assert_array_equal(raw[b * s * h * d:], 777.0)
+                grads[name] = raw[:b * s * h * d].reshape(b, s, h, d)
+        out.update(grads)
+    return out
+
+
+SHAPES = [  # b, h, sq, skv, d
+    (1, 1, 1, 1, 16), (2, 3, 32, 32, 16), (2, 2, 33, 47, 32), (1, 2, 100, 257, 64), (2, 2, 128, 128, 128),
+    (1, 3, 200, 130, 128), (3, 1, 31, 300, 16), (1, 1, 130, 5, 64), (1, 2, 512, 512, 128), (2, 8, 32, 128, 16),
+]
+
+
+@pytest.mark.parametrize('b,h,sq,skv,d', SHAPES)
+def test_core_vs_oracle(npm, b, h, sq, skv, d):
+    rng = np.random.default_rng(b * 1000 + sq * 7 + skv + d)
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k = rng.standard_normal([b, skv, h, d]).astype(np.float32)
+    v = rng.standard_normal([b, skv, h, d]).astype(np.float32)
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    q64, k64, v64, d64 = (x.astype(np.float64) for x in (q, k, v, dctx))
+    ctx, lse, probs = O.attention_core_fwd(q64, k64, v64, scale)
+    dq, dk, dv = O.attention_core_bwd(q64, k64, v64, probs, d64, scale)
+    got = _run_core(npm, q, k, v, scale, dctx=dctx, lse_ctx=(lse, ctx))
+    assert_close(got['ctx'], ctx, tol=2e-6)
+    np.testing.assert_allclose(got['lse'], lse, rtol=0, atol=3e-6)
+    assert_close(got['dv'], dv, tol=3e-6)
+    assert_close(got['dq'], dq, tol=3e-6)
+    assert_close(got['dk'], dk, tol=3e-6)
+    # end to end: the kernel's own lse / ctx feed its backward
+    own = _run_core(npm, q, k, v, scale, dctx=dctx)
+    for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+        assert_close(own[name], want, tol=3e-6, what=name)
+
+
+@pytest.mark.parametrize('b,h,s,d', [(2, 4, 96, 16), (1, 8, 160, 128), (2, 2, 64, 64)])
+def test_core_packed_operands_and_saved_scores(npm, b, h, s, d):
+    """q/k/v (and dq/dk/dv) as thirds of one [B, S, 3, H, D] buffer (row pitch 3 H D), and the variant that keeps
+    the raw scores for the backward instead of recomputing q.k."""
+    rng = np.random.default_rng(s + d)
+    q, k, v, dctx = (rng.standard_normal([b, s, h, d]).astype(np.float32) for _ in range(4))
+    scale = 1.0 / np.sqrt(d)
+    ctx, lse, probs = O.attention_core_fwd(*(x.astype(np.float64) for x in (q, k, v)), scale)
+    dq, dk, dv = O.attention_core_bwd(*(x.astype(np.float64) for x in (q, k, v)), probs, dctx.astype(np.float64), scale)
+    for save in (False, True):
+        got = _run_core(npm, q, k, v, scale, dctx=dctx, packed=True, save=save)
+        assert_close(got['ctx'], ctx, tol=2e-6)
+        for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+            assert_close(got[name], want, tol=3e-6, what=f'{name} save={save}')
+        if save:
+            raw = np.einsum('bqhd,bkhd->bhqk', q.astype(np.float64), k.astype(np.float64))
+            assert_close(got['scores'], raw, tol=2e-6)
+
+
+@pytest.mark.parametrize('b,h,sq,skv,d', [(2, 2, 40, 70, 16), (1, 2, 130, 130, 128), (2, 1, 64, 33, 32)])
+def test_core_masked(npm, b, h, sq, skv, d):
+    """np.where(mask, scaled, -inf) (attentions.py:105-107): causal, random, and broadcast masks; every row keeps
+    at least one position."""
+    rng = np.random.default_rng(sq + skv)
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k, v = (rng.standard_normal([b, skv, h, d]).astype(np.float32) for _ in range(2))
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    causal = np.tril(np.ones([sq, skv], dtype=bool))[None, None]                    # broadcast over batch and head
+    random = rng.random([b, h, sq, skv]) < 0.6
+    random[..., 0] = True
+    per_head = (rng.random([1, h, 1, skv]) < 0.7)
+    per_head[..., 3] = True
+    for mask in (causal, random, per_head):
+        full = np.broadcast_to(mask, (b, h, sq, skv))
+        ctx, lse, probs = O.attention_core_fwd(*(x.astype(np.float64) for x in (q, k, v)), scale, full)
+        dq, dk, dv = O.attention_core_bwd(*(x.astype(np.float64) for x in (q, k, v)), probs, dctx.astype(np.float64), scale)
+        for save in (False, True):
+            got = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save)
+            assert_close(got['ctx'], ctx, tol=2e-6)
+            np.testing.assert_allclose(got['lse'], lse, rtol=0, atol=3e-6)
+            for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+                assert_close(got[name], want, tol=3e-6, what=name)
+
+
+def test_core_rejects_unsupported_head_dim(npm):
+    from np_modeling_amd import _C, device as D
+    assert not D.mha_core_supported(24) and D.mha_core_supported(64) and not D.mha_core_supported(64, 32)
+    x = D.zeros([1, 4, 1, 24])
+    lse = D.zeros([4])
+    c = _C.npm_mha_core()
+    c.batch, c.heads, c.seq_q, c.seq_kv, c.head_dim, c.scale = 1, 1, 4, 4, 24, 0.2
+    c.q = c.k = c.v = c.ctx = x.ptr
+    c.q_pitch = c.k_pitch = c.v_pitch = c.ctx_pitch = 24
+    c.lse = lse.ptr
+    assert _C.lib().npm_mha_core_fwd(C.byref(c)) == 10003          # NPM_E_UNSUPPORTED
+    assert b'head_dim' in _C.lib().npm_last_error()
+
+
+def test_core_is_deterministic(npm):
+    """dQ is summed over key blocks by one wave in program order: two runs give the same bits."""
+    rng = np.random.default_rng(9)
+    q, k, v, dctx = (rng.standard_normal([2, 384, 2, 128]).astype(np.float32) for _ in range(4))
+    a = _run_core(npm, q, k, v, 0.09, dctx=dctx)
+    b = _run_core(npm, q, k, v, 0.09, dctx=dctx)
+    for name in ('ctx', 'lse', 'dq', 'dk', 'dv'):
+        np.testing.assert_array_equal(a[name], b[name])
+
+
+# ---- through the layer ------------------------------------------------------------------------------------
+_MHA = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+
+
+def _layer(npm, heads, feat, seed, kv_len=None):
+    np.random.seed(seed)
+    layer = npm.layers.MultiHeadAttention(num_heads=heads)
+    probe = np.zeros([1, 4, feat], dtype=np.float32)
+    layer(probe, np.zeros([1, kv_len and 4, feat], dtype=np.float32)) if kv_len else layer(probe)
+    p = {}
+    for n in _MHA:
+        arr = np.asarray(getattr(layer, '_' + n)) / (np.sqrt(feat) if n[0] == 'w' else 1.0)
+        p[n] = arr.astype(np.float32)
+    return layer, p
+
+
+@pytest.mark.parametrize('heads,feat,sq,skv', [(8, 128, 32, 32), (2, 256, 70, 70), (4, 128, 40, 100)])
+def test_layer_fused_core_equals_gemm_composition_and_oracle(npm, heads, feat, sq, skv):
+    from np_modeling_amd import device as D
+    rng = np.random.default_rng(sq)
+    cross = sq != skv
+    query = rng.standard_normal([3, sq, feat]).astype(np.float32)
+    kv = rng.standard_normal([3, skv, feat]).astype(np.float32) if cross else None
+    dy = rng.standard_normal([3, sq, feat]).astype(np.float32)
+    results = []
+    for core in (True, False):
+        D.ATTN_CORE = core
+        try:
+            layer, p = _layer(npm, heads, feat, 3)
+            for n in _MHA:
+                setattr(layer, '_' + n, p[n].copy())
+            out = np.asarray(layer(query, kv) if cross else layer(query))
+            assert layer._core is core
+            grads = [np.asarray(g) for g in layer(dy, backprop=True, learning_rate=0.05)]
+            results.append((out, grads, {n: np.asarray(getattr(layer, '_' + n)) for n in _MHA}))
+        finally:
+            D.ATTN_CORE = True
+    p64 = {n: p[n].astype(np.float64) for n in _MHA}
+    want, cache = O.mha_fwd(p64, query.astype(np.float64), None if kv is None else kv.astype(np.float64))
+    wg, pg = O.mha_bwd(p64, cache, dy.astype(np.float64))
+    for out, grads, params in results:
+        assert_close(out, want, tol=1e-5)
+        if cross:
+            assert_close(grads[0], wg[0], tol=1e-5)
+            assert_close(grads[1] + grads[2], wg[1] + wg[2], tol=1e-5)
+        else:
+            assert_close(sum(grads), sum(wg), tol=1e-5)
+        for n in _MHA:
+            assert_close(params[n], p64[n] - 0.05 * pg[n], tol=1e-5, what=n)
+
+
+def test_layer_masked_attention(npm):
+    """The layer's mask semantics (np_modeling_amd/layers/attentions.py docstring): a boolean array broadcastable
+    to [B, H, Sq, Skv]; forward and backward against the oracle's masked restatement."""
+    rng = np.random.default_rng(12)
+    heads, feat, b, s = 4, 64, 2, 48
+    layer, p = _layer(npm, heads, feat, 5)
+    for n in _MHA:
+        setattr(layer, '_' + n, p[n].copy())
+    query = rng.standard_normal([b, s, feat]).astype(np.float32)
+    dy = rng.standard_normal([b, s, feat]).astype(np.float32)
+    mask = np.tril(np.ones([s, s], dtype=bool))[None, None]
+    out = layer(query, mask=mask)
+    p64 = {n: p[n].astype(np.float64) for n in _MHA}
+    want, cache = O.mha_fwd(p64, query.astype(np.float64), mask=np.broadcast_to(mask, (b, heads, s, s)))
+    assert_close(out, want, tol=1e-5)
+    grads = [np.asarray(g) for g in layer(dy, backprop=True, learning_rate=0.05)]
+    wg, pg = O.mha_bwd(p64, cache, dy.astype(np.float64))
+    assert_close(sum(grads), sum(wg), tol=1e-5)
+    for n in _MHA:
+        assert_close(getattr(layer, '_' + n), p64[n] - 0.05 * pg[n], tol=1e-5, what=n)
+    # `if mask:` false in the reference: no mask
+    np.testing.assert_array_equal(np.asarray(layer(query, mask=False)), np.asarray(layer(query)))
+    with pytest.raises(AssertionError):
+        layer(query, mask=np.ones([b, heads, s + 1, s], dtype=bool))

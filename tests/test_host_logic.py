@@ -353,3 +353,37 @@ def test_loss_reads_refilled_targets(npm):
     assert mse(y, targets) == pytest.approx(1.0)
     targets[:] = 1.0
     assert mse(y, targets) == pytest.approx(0.0)
+
+
+@pytest.mark.parametrize('masked', [False, True])
+def test_mha_fused_core_path_on_simulator(npm, masked):
+    """Head size 16 takes the fused attention core (npm_mha_core_*): operand descriptors of the packed and the
+    cross-attention layouts, the mask plumbing, against the oracle."""
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(1)
+    names = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
+    for kv_len in (None, 9):
+        np.random.seed(0)
+        layer = npm.layers.MultiHeadAttention(num_heads=2)
+        x = rng.standard_normal([2, 6, 32]).astype(np.float32)
+        kv = None if kv_len is None else rng.standard_normal([2, kv_len, 32]).astype(np.float32)
+        skv = kv_len or 6
+        mask = (rng.random([2, 2, 6, skv]) < 0.7) if masked else None
+        if masked:
+            mask[..., 0] = True
+        layer(x, kv) if kv is not None else layer(x)                      # lazy init
+        for n in names[:4]:       # O(1) scores: the simulator keeps the log-sum-exp in fp32, like the kernel
+            getattr(layer, '_' + n).set(np.asarray(getattr(layer, '_' + n)) / np.float32(6.0))
+        out = layer(x, kv, mask=mask) if kv is not None else layer(x, mask=mask)
+        assert layer._core and 'npm_mha_core_fwd' in npm._C._LIB.calls
+        assert layer._packed is (kv is None)
+        p = {n: np.asarray(getattr(layer, '_' + n)).astype(np.float64) for n in names}
+        want, cache = O.mha_fwd(p, x.astype(np.float64), None if kv is None else kv.astype(np.float64), mask=mask)
+        assert_close(out, want, tol=1e-6)
+        dy = rng.standard_normal([2, 6, 32]).astype(np.float32)
+        dq, dk, dv = layer(dy, backprop=True, learning_rate=0.1)
+        (wq_, wk_, wv_), grads = O.mha_bwd(p, cache, dy.astype(np.float64))
+        assert_close(dq, wq_, tol=1e-6)
+        assert_close(np.asarray(dk) + np.asarray(dv), wk_ + wv_, tol=1e-6)
+        for n in names:
+            assert_close(getattr(layer, '_' + n), p[n] - 0.1 * grads[n], tol=1e-6, what=n)

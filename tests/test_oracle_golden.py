@@ -192,3 +192,35 @@ def test_losses():
     close(O.mse_bwd(g['y'], g['t']), g['mse_grad'])
     np.testing.assert_allclose(O.xent_fwd(g['prob'], g['onehot']), g['ce'], rtol=1e-6)
     close(O.xent_bwd(g['prob'], g['onehot']), g['ce_grad'])
+
+
+def test_attention_core_restatements_agree():
+    """The one-shot attention core (attentions.py:103-112) and the blockwise online-softmax forward the reference
+    derives in attentions_test.py:194-246 are the same function; the core composed with the projections is
+    mha_fwd / mha_bwd, which the golden MHA fixtures pin."""
+    rng = np.random.default_rng(0)
+    q = rng.standard_normal([2, 70, 3, 16])
+    k, v = rng.standard_normal([2, 45, 3, 16]), rng.standard_normal([2, 45, 3, 16])
+    scale = 0.25
+    ctx, lse, probs = O.attention_core_fwd(q, k, v, scale)
+    ctx2, lse2 = O.attention_core_fwd_blockwise(q, k, v, scale)
+    np.testing.assert_allclose(ctx2, ctx, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(lse2, lse, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(probs.sum(-1), 1.0, atol=1e-12)
+    # against the golden self-attention fixture: the middle of mha_fwd / mha_bwd IS the core
+    g = load_golden('mha_self')
+    p = {n: g[n + '0'].astype(np.float64) for n in O.MHA_PARAM_NAMES}
+    out, cache = O.mha_fwd(p, g['query'].astype(np.float64))
+    core_ctx, _, core_probs = O.attention_core_fwd(cache['q'], cache['k'], cache['v'], 1 / np.sqrt(cache['q'].shape[-1]))
+    np.testing.assert_allclose(core_probs, cache['scores'], atol=1e-12)
+    np.testing.assert_allclose(core_ctx.transpose(0, 2, 1, 3), cache['values'], atol=1e-12)
+    # the gradient against central differences of the forward (moderate scores: the random operands above)
+    dctx = rng.standard_normal(ctx.shape)
+    dq, dk, dv = O.attention_core_bwd(q, k, v, probs, dctx, scale)
+    eps = 1e-6
+    for which, grad, idx in ((0, dq, (1, 3, 2, 5)), (2, dv, (0, 7, 1, 2)), (1, dk, (1, 4, 0, 1))):
+        def loss(delta):
+            ops = [q.copy(), k.copy(), v.copy()]
+            ops[which][idx] += delta
+            return (O.attention_core_fwd(*ops, scale)[0] * dctx).sum()
+        np.testing.assert_allclose((loss(eps) - loss(-eps)) / (2 * eps), grad[idx], rtol=1e-5, atol=1e-8)

@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Times the fused attention core (npm_mha_core_fwd / npm_mha_core_bwd) and the GEMM composition it replaces at
+the C4 / C5 attention shape (B 256, H 8, S 512, D 128 by default), fp32-MFMA peak 157.3 TF as the denominator.
+FLOPs counted: forward 2 products, backward 4 (the recomputed q.k is not algorithmic work)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import np_modeling_amd as npm  # noqa: E402
+from np_modeling_amd import device as D  # noqa: E402
+from np_modeling_amd.device import Mat  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument('--b', type=int, default=256)
+ap.add_argument('--h', type=int, default=8)
+ap.add_argument('--s', type=int, default=512)
+ap.add_argument('--d', type=int, default=128)
+ap.add_argument('--reps', type=int, default=5)
+ap.add_argument('--save-scores', action='store_true')
+ap.add_argument('--tune', default='')
+a = ap.parse_args()
+for item in filter(None, a.tune.split(',')):
+    knob, value = item.split('=')
+    npm._C.check(npm._C.lib().npm_set_tuning(int(knob), int(value)))
+b, h, s, d = a.b, a.h, a.s, a.d
+rng = np.random.default_rng(0)
+qkv = D.from_host(rng.standard_normal([b, s, 3, h, d], dtype=np.float32))
+f = h * d
+q, k, v = qkv, qkv.flat_view(f, [qkv.size - f]), qkv.flat_view(2 * f, [qkv.size - 2 * f])
+dctx = D.from_host(rng.standard_normal([b, s, h, d], dtype=np.float32))
+dqkv = D.empty([b, s, 3, h, d])
+dq, dk, dv = dqkv, dqkv.flat_view(f, [dqkv.size - f]), dqkv.flat_view(2 * f, [dqkv.size - 2 * f])
+dims = (b, h, s, s, d)
+scale = 1.0 / np.sqrt(d)
+for name in ('fwd', 'bwd'):
+    for rep in range(a.reps + 1):
+        with D.KernelTimer() as t:
+            if name == 'fwd':
+                ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, save_scores=a.save_scores)
+            else:
+                D.mha_core_bwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), ctx, lse, dctx, Mat(dq, 3 * f), Mat(dk, 3 * f),
+                               Mat(dv, 3 * f), dims, scale, scores=scores)
+        rec = list(t.summary().values())[0]
+        if rep:
+            print(f'mha_core_{name}: {rec["ms"]:.3f} ms  {rec["flops"] / rec["ms"] / 1e9:.1f} TF  '
+                  f'({rec["flops"] / rec["ms"] / 1e9 / 157.3:.1%} of the fp32-MFMA peak)', flush=True)

@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Where one query tile of the attention backward spends its cycles: in-kernel s_memtime stamps at the phase
+boundaries (npm_debug_attn_trace), median over blocks, at the C4 / C5 attention shape."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import np_modeling_amd as npm  # noqa: E402
+from np_modeling_amd import _C, device as D  # noqa: E402
+from np_modeling_amd.device import Mat  # noqa: E402
+
+b, h, s, d = 256, 8, 512, 128
+rng = np.random.default_rng(0)
+qkv = D.from_host(rng.standard_normal([b, s, 3, h, d], dtype=np.float32))
+f = h * d
+q, k, v = qkv, qkv.flat_view(f, [qkv.size - f]), qkv.flat_view(2 * f, [qkv.size - 2 * f])
+dctx = D.from_host(rng.standard_normal([b, s, h, d], dtype=np.float32))
+dqkv = D.empty([b, s, 3, h, d])
+dq, dk, dv = dqkv, dqkv.flat_view(f, [dqkv.size - f]), dqkv.flat_view(2 * f, [dqkv.size - 2 * f])
+dims = (b, h, s, s, d)
+scale = 1.0 / np.sqrt(d)
+ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, save_scores='--save-scores' in sys.argv)
+nblocks = b * h
+trace = D._Buffer(8 * 16 * nblocks)
+lib = _C.lib()
+for rep in range(3):
+    _C.check(lib.npm_debug_attn_trace(trace.ptr))
+    D.mha_core_bwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), ctx, lse, dctx, Mat(dq, 3 * f), Mat(dk, 3 * f), Mat(dv, 3 * f), dims, scale, scores=scores)
+    D.synchronize()
+    _C.check(lib.npm_debug_attn_trace(None))
+host = np.zeros([nblocks, 16], dtype=np.int64)
+_C.check(lib.npm_d2h(host.ctypes.data, trace.ptr, host.nbytes))
+names = ['S = Q K^T (+next DMA)', 'dP = dO V^T (+exp)', 'dV (+dS to LDS)', 'barrier (dS)', 'dQ chain', 'dK (+dQ stores)', '-', 'to next tile start']
+order = [0, 1, 2, 3, 4, 5, 6, 7, 8]
+dt = np.diff(host[:, order], axis=1)
+print('phase                      median   p10    p90   (cycles; 64 MFMAs = 4096 cycles at the pipe rate)')
+for i, n in enumerate(names):
+    col = dt[:, i]
+    print(f'{n:26s} {np.median(col):7.0f} {np.percentile(col, 10):6.0f} {np.percentile(col, 90):6.0f}')
+print(f'tile total                 {np.median(host[:, 8] - host[:, 0]):7.0f}   (5 x 4096 = 20480 at the pipe rate)')
