@@ -144,7 +144,12 @@ int npm_set_tuning(int knob, int value);
  *                         4096 accumulated terms (visible in column checksums, not per element). */
 enum { NPM_MATH_F32 = 0, NPM_MATH_BF16X3_FAST = 1, NPM_MATH_BF16X3 = 2 };
 int npm_set_math(int mode);
-int npm_get_math(void);
+int npm_get_math(void);                  /* the mode REQUESTED with npm_set_math */
+/* The mode the most recent npm_sgemm / npm_conv2d_* / npm_mha_core_* launch actually RAN.  The split-bf16 modes exist
+ * on the LDS-DMA pipelines with the 128 x 128 tile; a launch that cannot take them (operands not 16-byte aligned, K not a
+ * multiple of 16, the epilogue column sums `colsum`, the 128 x 256 tile, the fused attention core) runs the exact-f32
+ * MFMA and says so here -- results are then bit-equal to NPM_MATH_F32. */
+int npm_last_math(void);
 /* Diagnostics: when buf != NULL every block of the LDS-DMA GEMM writes 8 words (hardware id, XCC id, s_memtime at
  * start / first tile landed / loop end / after the epilogue stores) to buf[blockIdx*8 ..]; NULL switches it off. */
 int npm_debug_gemm_trace(long long *buf);
@@ -245,6 +250,11 @@ int npm_xent_fwd(const float *y, const float *targets, size_t n, double *loss);
 int npm_xent_bwd(const float *y, const float *targets, float *dy, size_t n);
 /* DropOut (normalizations.py:14-30): y = mask ? x / keep_prob : 0 with a host-drawn byte mask */
 int npm_mask_scale(const float *x, const unsigned char *mask, float *y, size_t n, float keep_prob);
+/* The same with the mask drawn ON THE DEVICE: element i keeps its value when word (i & 3) of
+ * Philox4x32-10(counter = (i / 4, offset), key = seed) is below keep_prob * 2^32; the byte mask is written too (the layer's
+ * `_mask` stays readable).  Deterministic in (seed, offset); not the host generator's stream -- seeded parity with the
+ * reference needs the host-drawn path above. */
+int npm_dropout_philox(const float *x, float *y, unsigned char *mask, size_t n, float keep_prob, uint64_t seed, uint64_t offset);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,7 @@ SIGNATURES = {
     'npm_set_tuning': [C.c_int, C.c_int],
     'npm_set_math': [C.c_int],
     'npm_get_math': [],
+    'npm_last_math': [],
     'npm_debug_gemm_trace': [_P],
     'npm_debug_attn_trace': [_P],
     'npm_relu_fwd': [_P, _P, _SZ],
@@ -126,6 +127,7 @@ SIGNATURES = {
     'npm_xent_fwd': [_P, _P, _SZ, C.POINTER(C.c_double)],
     'npm_xent_bwd': [_P, _P, _P, _SZ],
     'npm_mask_scale': [_P, _P, _P, _SZ, _F],
+    'npm_dropout_philox': [_P, _P, _P, _SZ, _F, C.c_uint64, C.c_uint64],
 }
 _SPECIAL = {
     'npm_abi_version': (C.c_int, []),
@@ -257,6 +259,12 @@ def set_math(mode: str) -> None:
 
 def get_math() -> str:
     value = lib().npm_get_math()
+    return next(name for name, v in MATH_MODES.items() if v == value)
+
+
+def last_math() -> str:
+    """The arithmetic the most recent matrix-product launch actually ran (include/npm_hip.h npm_last_math)."""
+    value = lib().npm_last_math()
     return next(name for name, v in MATH_MODES.items() if v == value)
 
 

@@ -19,7 +19,8 @@ __version__ = '0.1.0'
 from np_modeling_amd import _C, device, parallel          # noqa: E402,F401
 from np_modeling_amd import optimizer, layers, loss, train  # noqa: E402,F401
 from np_modeling_amd.device import DeviceArray, as_device, synchronize  # noqa: E402,F401
-from np_modeling_amd._C import set_math, get_math  # noqa: E402,F401
+from np_modeling_amd._C import set_math, get_math, last_math  # noqa: E402,F401
+from np_modeling_amd.layers.normalizations import set_dropout_rng  # noqa: E402,F401
 
 
 def install(include_support_modules: bool = False) -> None:

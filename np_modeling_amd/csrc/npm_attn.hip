@@ -754,6 +754,7 @@ extern "C" int npm_mha_core_fwd(const npm_mha_core *c) {
     if ((long)a.batch * a.heads * a.q_tiles == 0) return NPM_OK;
     NPM_ARG((long)a.batch * a.heads * a.q_tiles < (1L << 31));
     hipStream_t s = npm::ctx().stream;
+    npm::note_math(NPM_MATH_F32);
     switch (c->head_dim) {
         case 16: return launch_fwd<16>(a, s);
         case 32: return launch_fwd<32>(a, s);
@@ -778,6 +779,7 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
     hipLaunchKernelGGL(mha_delta_kernel, dim3((int)((rows * 32 + 255) / 256)), dim3(256), 0, s, a.dctx, a.dctx_pitch,
                        (const float *)a.ctx, a.ctx_pitch, a.delta, (long)a.batch, (long)a.seq_q, a.heads, c->head_dim);
     NPM_CHECK_LAUNCH();
+    npm::note_math(NPM_MATH_F32);
     switch (c->head_dim) {
         case 16: return launch_bwd<16>(a, s);
         case 32: return launch_bwd<32>(a, s);

@@ -447,6 +447,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     }
     const long grid = (long)a.tiles_m * a.tiles_n;
     NPM_ARG(grid < (1L << 31));
+    npm::note_math((tall || dma) ? g_conv_math : 0);
     if (tall && g_conv_math == 2) hipLaunchKernelGGL((conv_fwd_glds_kernel<true, 2>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else if (tall && g_conv_math == 1) hipLaunchKernelGGL((conv_fwd_glds_kernel<true, 1>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
     else if (tall) hipLaunchKernelGGL((conv_fwd_glds_kernel<true, 0>), dim3((int)grid), dim3(NTHREADS), 0, s, a);
@@ -550,6 +551,7 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
     const bool dma = g_conv_dma && vec && pixels % GK == 0 && a.k_per_split % GK == 0 &&
                      ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) &&
                      (long)a.k_per_split * c_out * 4 < (1L << 30);
+    npm::note_math(dma ? g_conv_math : 0);
     if (dma && g_conv_math == 2) hipLaunchKernelGGL(conv_wgrad_glds_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
     else if (dma && g_conv_math == 1) hipLaunchKernelGGL(conv_wgrad_glds_kernel<1>, dim3(grid), dim3(NTHREADS), 0, s, a);
     else if (dma) hipLaunchKernelGGL(conv_wgrad_glds_kernel<0>, dim3(grid), dim3(NTHREADS), 0, s, a);

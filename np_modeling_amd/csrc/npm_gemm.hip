@@ -339,6 +339,11 @@ inline bool aligned16(const void *ptr) { return ((uintptr_t)ptr & 15) == 0; }
 
 template <bool A_KMAJ, bool B_KMAJ>
 void launch(const GemmArgs &a, bool vec, bool dma, int grid, hipStream_t stream) {
+    // The split-bf16 modes exist on the LDS-DMA pipeline with the 128 x 128 tile (with or without the fused k-sums);
+    // the wide tile, the epilogue column sums and the register-staged fallback (unaligned operands, K % 16 != 0) run
+    // the exact-f32 MFMA whatever was requested: npm_last_math() tells which it was.
+    const bool math_honoured = dma && (a.ksum || (!a.wide && !a.e.cs));
+    npm::note_math(math_honoured ? a.math : 0);
     if (dma && a.ksum) {
         if constexpr (!A_KMAJ && !B_KMAJ) {
             if (a.math == 1) {

@@ -26,6 +26,8 @@ int fail(int code, const char *fmt, ...);
 int colsum_launch(const float *x, float *out, long rows, long cols, long ld);
 void set_ln_bwd_blocks(int blocks_per_cu);
 void set_ew_grid_cap(int blocks);
+// the arithmetic the most recent matrix-product launch actually ran (npm_last_math): NPM_MATH_*
+void note_math(int mode);
 
 // Pool-backed scratch for split-K slabs and reduction partials; released on scope exit.
 // Safe because every launch goes to the single compute stream (stream-ordered reuse).

@@ -12,6 +12,10 @@ namespace npm {
 
 static thread_local char g_error[512] = "";
 
+static int g_last_math = 0;
+void note_math(int mode) { g_last_math = mode; }
+int last_math() { return g_last_math; }
+
 Context &ctx() {
     static Context c;
     return c;
@@ -252,3 +256,6 @@ int npm_event_elapsed_ms(void *start, void *stop, float *ms) {
 }
 
 }  // extern "C"
+
+namespace npm { int last_math(); }
+extern "C" int npm_last_math(void) { return npm::last_math(); }

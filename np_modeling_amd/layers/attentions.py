@@ -183,11 +183,13 @@ class MultiHeadAttention(layer.StatefulLayer):
         with parallel.grad_scope(self._numel()) as scope:
             return self._backward_impl(D.as_device(dy), optimizer_, scope)
 
-    def _backward_impl(self, dy, optimizer_, scope, *, sum_inputs: bool = False,
+    def _backward_impl(self, dy, optimizer_, scope, *, sum_inputs: bool = False, sum_kv: bool = False,
                        residual: Optional[D.DeviceArray] = None):
         """Returns (dquery, dkey, dvalue) (attentions.py:199), or -- for a composite that feeds
         one tensor as query, key and value -- their sum (+ residual) accumulated in the GEMM
-        epilogues when ``sum_inputs`` is set (reference layers/transformer.py:84-85)."""
+        epilogues when ``sum_inputs`` is set (reference layers/transformer.py:84-85).  ``sum_kv``
+        (cross-attention over one kv tensor): returns (dquery (+ residual), dkey + dvalue), the second
+        accumulated in its GEMMs' epilogues (transformer.py:186)."""
         h, dk, dv = self._num_heads, self._key_dim, self._value_dim
         query, key, value = self._query, self._key, self._value
         q, k, v, scores, ctx = self._q, self._k, self._v, self._attention_scores, self._context
@@ -269,6 +271,14 @@ class MultiHeadAttention(layer.StatefulLayer):
                 D.gemm(m_kv, f, h * dk, Mat(dk_, gk), Mat(wk, f), Mat(total, f), residual=Mat(total, f))
                 D.gemm(m_kv, fv, h * dv, Mat(dv_, gv), Mat(wv, fv), Mat(total, fv), residual=Mat(total, fv))
             result = total
+        elif sum_kv:
+            assert key is value and fv == f
+            dquery, dkv = D.empty([b, sq, f]), D.empty([b, skv, f])
+            D.gemm(m_q, f, h * dk, Mat(dq, gq), Mat(wq, f), Mat(dquery, f),
+                   residual=None if residual is None else Mat(residual, f))
+            D.gemm(m_kv, f, h * dk, Mat(dk_, gk), Mat(wk, f), Mat(dkv, f))
+            D.gemm(m_kv, f, h * dv, Mat(dv_, gv), Mat(wv, f), Mat(dkv, f), residual=Mat(dkv, f))
+            result = (dquery, dkv)
         else:
             assert residual is None
             dquery, dkey, dvalue = D.empty([b, sq, f]), D.empty([b, skv, f]), D.empty([b, skv, fv])

@@ -53,14 +53,11 @@ class Linear(layer.StatefulLayer):
     def _backward_impl(self, dy: D.DeviceArray, optimizer_, scope, *,
                        relu_mask_pre: Optional[D.DeviceArray] = None,
                        residual: Optional[D.DeviceArray] = None,
-                       need_dx: bool = True, db: Optional[D.DeviceArray] = None,
-                       dx_colsum_out: Optional[D.DeviceArray] = None) -> Optional[D.DeviceArray]:
+                       need_dx: bool = True, db: Optional[D.DeviceArray] = None) -> Optional[D.DeviceArray]:
         """db, dw, dx of mlp.py:34-36.  ``relu_mask_pre``: zero dx where that (the producer's
         pre-activation) is negative -- the upstream Dense's ReLU backward fused into this
         GEMM's epilogue.  ``residual``: dx += residual (a skip connection's gradient).
-        ``db``: the bias gradient already taken by whoever produced ``dy`` (skips the column sum);
-        ``dx_colsum_out``: take the column sums of dx in this GEMM's epilogue (the upstream
-        layer's bias gradient)."""
+        ``db``: the bias gradient already taken by whoever produced ``dy`` (skips the column sum)."""
         w = self._param('_w')
         x = self._x
         k, n = w.shape
@@ -78,8 +75,7 @@ class Linear(layer.StatefulLayer):
             dx = D.empty([m, k])
             D.gemm(m, k, n, Mat(dy, n), Mat(w, n), Mat(dx, k), trans_b=True,       # dy @ w^T
                    residual=None if residual is None else Mat(residual, k),
-                   relu_mask=None if relu_mask_pre is None else Mat(relu_mask_pre, k),
-                   colsum_out=dx_colsum_out)
+                   relu_mask=None if relu_mask_pre is None else Mat(relu_mask_pre, k))
             assert dx.shape == x.shape
         scope.defer(optimizer_, self, '_w', dw)
         scope.defer(optimizer_, self, '_b', db)

@@ -12,16 +12,53 @@ from np_modeling_amd import parallel
 from np_modeling_amd.layers import layer
 
 
+class _DeviceRng:
+    """State of the device-side mask generator (csrc/npm_optim.hip dropout_philox_kernel): a seed and a running
+    offset, one offset per forward call, so every call draws an independent stream and a run is reproducible from
+    its seed.  Off by default: the reference draws masks with the HOST generator (np.random.binomial), and seeded
+    parity with it needs that path."""
+
+    enabled = False
+    seed = 0
+    offset = 0
+
+
+def set_dropout_rng(kind: str = 'host', seed: int = 0) -> None:
+    """``'host'``: masks from NumPy's global generator with the reference's exact call (default; seeded runs drop the
+    same elements as the reference).  ``'device'``: masks drawn on the GPU by Philox4x32-10 -- no host draw, no PCIe
+    upload of a mask per forward; ``_mask`` stays readable (copied to the host on access)."""
+    if kind not in ('host', 'device'):
+        raise ValueError("set_dropout_rng: kind is 'host' or 'device'")
+    _DeviceRng.enabled = kind == 'device'
+    _DeviceRng.seed, _DeviceRng.offset = int(seed), 0
+
+
 class DropOut(layer.Layer):
     """``drop_prob == 0`` is the identity and returns its argument unchanged
     (normalizations.py:14-23) -- the only path the encoder exercises.  For p > 0 the mask is
     drawn on the HOST with the reference's exact call (``np.random.binomial``), so a seeded run
     drops the same elements and ``_mask`` stays a readable NumPy array (reference
-    layers/normalizations_test.py:15-30 reads it); applying it is one device kernel."""
+    layers/normalizations_test.py:15-30 reads it); applying it is one device kernel.
+    :func:`set_dropout_rng` switches to masks drawn on the device."""
 
     def __init__(self, drop_prob: float, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._drop_prob = drop_prob
+        self._host_mask = None
+        self._mask_dev = None
+
+    @property
+    def _mask(self):
+        """The 0/1 mask of the last forward as a NumPy array (device-drawn masks are copied to the host here)."""
+        if self._host_mask is None and self._mask_dev is not None:
+            raw = np.empty(self._mask_dev.nbytes, dtype=np.uint8)
+            _C.check(_C.lib().npm_d2h(raw.ctypes.data, self._mask_dev.ptr, raw.nbytes), 'npm_d2h')
+            self._host_mask = raw.reshape(self._mask_shape).astype(np.int64)
+        return self._host_mask
+
+    @_mask.setter
+    def _mask(self, value):
+        self._host_mask = value
 
     def _apply(self, x):
         keep = 1 - self._drop_prob
@@ -33,6 +70,14 @@ class DropOut(layer.Layer):
     def forward(self, x, training: bool = True):
         if training and self._drop_prob != 0.0:
             keep = 1 - self._drop_prob
+            if _DeviceRng.enabled:
+                x = D.as_device(x)
+                out = D.empty(x.shape)
+                self._mask_dev, self._mask_shape, self._host_mask = D.ByteBuffer(x.size), tuple(x.shape), None
+                _C.check(_C.lib().npm_dropout_philox(x.ptr, out.ptr, self._mask_dev.ptr, x.size, float(keep),
+                                                     _DeviceRng.seed, _DeviceRng.offset), 'npm_dropout_philox')
+                _DeviceRng.offset += 1
+                return out
             self._mask = np.random.binomial(n=1, p=keep, size=x.size).reshape(x.shape)
             self._mask_dev = D.bytes_from_host(self._mask.astype(np.uint8))
             return self._apply(x)

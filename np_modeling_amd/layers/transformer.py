@@ -2,7 +2,7 @@
 
 Composition only: the sub-layers do the arithmetic.  With ``drop_rate == 0`` (the only
 configuration the reference's tests and the benchmark use) the residual additions of
-transformer.py:39,53,78,90 and the three-way sum of transformer.py:85 are folded into GEMM
+transformer.py:39,53,78,90 (encoder; 130,141,152,170-198 decoder) and the three-way sum of transformer.py:85 are folded into GEMM
 epilogues / the LayerNorm backward kernel, and the ReLU backward of ``dense1`` is folded
 into the epilogue of ``dense2``'s dx GEMM, so no standalone elementwise pass runs.
 All parameter updates are deferred to the end of ``backward`` (every dx is computed from
@@ -188,9 +188,47 @@ class TransformerDecoder(layer.Layer):
     def _feed_forward(self, x):
         return self._dense2(self._dense1(x))
 
+    @staticmethod
+    def _ensure(sub, *args):
+        if not sub._initialized:
+            sub.initialize(*args)
+            sub._initialized = True
+
+    def _fusable(self) -> bool:
+        return _identity_dropout(self._dropout1, self._dropout2, self._dropout3) and self._dense1._fused_relu()
+
     def forward(self, q, kv):
-        """Three residual blocks: self-attention, cross-attention over ``kv``, feed-forward (transformer.py:120-157)."""
+        """Three residual blocks: self-attention, cross-attention over ``kv``, feed-forward (transformer.py:120-157).
+        Without dropout the residual additions ride the producing GEMMs' epilogues, as in the encoder."""
         q, kv = D.as_device(q), D.as_device(kv)
+        if not self._fusable():
+            return self._forward_unfused(q, kv)
+        batch, seq_len_q, features = q.shape
+        pre = self._norm_first
+        sa, ca, dense1, dense2 = self._self_attention, self._cross_attention, self._dense1, self._dense2
+        self._kv = kv
+        h = self._norm1(q) if pre else q
+        self._ensure(sa, h)
+        out = sa._forward_impl(h, h, h, residual=q)                       # ... + skip (transformer.py:130)
+        if not pre:
+            out = self._norm1(out)
+        skip = out
+        h = self._norm2(out) if pre else out
+        self._ensure(ca, h, kv)
+        out = ca._forward_impl(h, kv, kv, residual=skip)                  # ... + skip (transformer.py:141)
+        if not pre:
+            out = self._norm2(out)
+        out = out.reshape(-1, features)
+        skip = out
+        h = self._norm3(out) if pre else out
+        h = dense1(h)
+        self._ensure(dense2, h)
+        out = dense2._forward_impl(h, residual=skip)                      # ... + skip (transformer.py:152)
+        if not pre:
+            out = self._norm3(out)
+        return out.reshape(batch, seq_len_q, features)
+
+    def _forward_unfused(self, q, kv):
         batch, seq_len_q, features = q.shape
         out = _block_forward(q, self._norm1, self._dropout1, self._norm_first, self._self_attention)
         out = _block_forward(out, self._norm2, self._dropout2, self._norm_first,
@@ -202,6 +240,49 @@ class TransformerDecoder(layer.Layer):
     def backward(self, dy, optimizer_):
         """Returns ``(dq, dkv)``; ``dkv`` is the cross-attention's dkey + dvalue (transformer.py:159-203)."""
         dy = D.as_device(dy)
+        with parallel.grad_scope(0) as scope:
+            if self._fusable():
+                return self._backward_fused(dy, optimizer_, scope)
+            return self._backward_unfused(dy, optimizer_, scope)
+
+    def _backward_fused(self, dy, optimizer_, scope):
+        """Mirror of the fused forward: skip-connection gradients ride the LayerNorm backward (pre-norm) or the
+        input-gradient GEMMs (post-norm); dense1's ReLU backward is the mask epilogue of dense2's dx GEMM; the
+        cross-attention's dkey + dvalue and the self-attention's dq + dk + dv accumulate in GEMM epilogues."""
+        batch, seq_len_q, features = dy.shape
+        pre = self._norm_first
+        sa, ca, lin1, lin2 = self._self_attention, self._cross_attention, self._dense1._linear, self._dense2
+        dy = dy.reshape(-1, features)
+        if not pre:
+            dy = self._norm3._backward_impl(dy, optimizer_, scope)
+        dskip = dy
+        dh = lin2._backward_impl(dy, optimizer_, scope, relu_mask_pre=self._dense1._activation._x)
+        scope.flush()
+        if pre:
+            dy = self._norm3._backward_impl(lin1._backward_impl(dh, optimizer_, scope), optimizer_, scope, residual=dskip)
+        else:
+            dy = lin1._backward_impl(dh, optimizer_, scope, residual=dskip)
+        scope.flush()
+        dy = dy.reshape(batch, seq_len_q, features)
+        if not pre:
+            dy = self._norm2._backward_impl(dy, optimizer_, scope)
+        dskip = dy
+        if pre:
+            dquery, dkv = ca._backward_impl(dy, optimizer_, scope, sum_kv=True)
+            dy = self._norm2._backward_impl(dquery, optimizer_, scope, residual=dskip)
+        else:
+            dy, dkv = ca._backward_impl(dy, optimizer_, scope, sum_kv=True, residual=dskip)
+        if not pre:
+            dy = self._norm1._backward_impl(dy, optimizer_, scope)
+        dskip = dy
+        if pre:
+            dy = sa._backward_impl(dy, optimizer_, scope, sum_inputs=True)
+            dy = self._norm1._backward_impl(dy, optimizer_, scope, residual=dskip)
+        else:
+            dy = sa._backward_impl(dy, optimizer_, scope, sum_inputs=True, residual=dskip)
+        return dy, dkv
+
+    def _backward_unfused(self, dy, optimizer_, scope):
         batch, seq_len_q, features = dy.shape
         kv_grad = []
 
@@ -218,11 +299,10 @@ class TransformerDecoder(layer.Layer):
         def self_attention_backward(g):
             return D.add3(*self._self_attention._backward_impl(g, optimizer_, scope))
 
-        with parallel.grad_scope(0) as scope:
-            dy = _block_backward(dy.reshape(-1, features), self._norm3, self._dropout3, self._norm_first,
-                                 feed_forward_backward, optimizer_, scope)
-            dy = _block_backward(dy.reshape(batch, seq_len_q, features), self._norm2, self._dropout2,
-                                 self._norm_first, cross_attention_backward, optimizer_, scope)
-            dy = _block_backward(dy, self._norm1, self._dropout1, self._norm_first, self_attention_backward,
-                                 optimizer_, scope)
+        dy = _block_backward(dy.reshape(-1, features), self._norm3, self._dropout3, self._norm_first,
+                             feed_forward_backward, optimizer_, scope)
+        dy = _block_backward(dy.reshape(batch, seq_len_q, features), self._norm2, self._dropout2,
+                             self._norm_first, cross_attention_backward, optimizer_, scope)
+        dy = _block_backward(dy, self._norm1, self._dropout1, self._norm_first, self_attention_backward,
+                             optimizer_, scope)
         return dy, kv_grad[0]

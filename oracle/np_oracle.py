@@ -580,6 +580,47 @@ def decoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3, verbatim: 
 # --------------------------------------------------------------------------- #
 # optimizers and losses (reference optimizer.py:26-69, loss.py:20-39)
 # --------------------------------------------------------------------------- #
+# --------------------------------------------------------------------------- #
+# DropOut (reference layers/normalizations.py:14-30) and the device-side mask generator
+# --------------------------------------------------------------------------- #
+def dropout_apply(x: Array, mask: Array, keep_prob: float) -> Array:
+    """np.where(mask, x / keep_prob, 0) (normalizations.py:21-23, and :27-30 for the gradient)."""
+    return np.where(mask, x / keep_prob, 0.0)
+
+
+def philox4x32_10(counter: Array, key) -> Array:
+    """Philox4x32-10 of Salmon, Moraes, Dror, Shaw, "Parallel random numbers: as easy as 1, 2, 3" (SC'11), the
+    generator csrc/npm_optim.hip draws dropout masks with.  ``counter`` [..., 4] uint32, ``key`` (k0, k1); returns
+    [..., 4] uint32.  Pinned by the published known-answer vectors in tests/test_oracle_golden.py."""
+    c = np.array(counter, dtype=np.uint64) & 0xFFFFFFFF
+    k0, k1 = np.uint64(int(key[0]) & 0xFFFFFFFF), np.uint64(int(key[1]) & 0xFFFFFFFF)
+    mask32 = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c[..., 0]
+        p1 = np.uint64(0xCD9E8D57) * c[..., 2]
+        n0 = (p1 >> np.uint64(32)) ^ c[..., 1] ^ k0
+        n2 = (p0 >> np.uint64(32)) ^ c[..., 3] ^ k1
+        c = np.stack([n0 & mask32, p1 & mask32, n2 & mask32, p0 & mask32], axis=-1)
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask32
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask32
+    return c.astype(np.uint32)
+
+
+def dropout_philox_mask(n: int, keep_prob: float, seed: int, offset: int) -> Array:
+    """The byte mask npm_dropout_philox draws for n elements: element i keeps its value when word i & 3 of
+    Philox4x32-10(counter = (i // 4 lo, i // 4 hi, offset lo, offset hi), key = (seed lo, seed hi)) is below
+    keep_prob * 2^32 (keep_prob as fp32, the threshold formed in fp64 and truncated)."""
+    groups = (n + 3) // 4
+    g = np.arange(groups, dtype=np.uint64)
+    counter = np.stack([g & np.uint64(0xFFFFFFFF), g >> np.uint64(32),
+                        np.full(groups, offset & 0xFFFFFFFF, dtype=np.uint64),
+                        np.full(groups, (offset >> 32) & 0xFFFFFFFF, dtype=np.uint64)], axis=-1)
+    words = philox4x32_10(counter, (seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF)).reshape(-1)[:n]
+    scaled = float(np.float32(keep_prob)) * 4294967296.0
+    threshold = 4294967296 if scaled >= 4294967296.0 else int(scaled)
+    return words.astype(np.uint64) < np.uint64(threshold)
+
+
 def sgd_step(param: Array, grad: Array, lr: float) -> Array:
     """v -= lr * g, in the parameter's own dtype (optimizer.py:32)."""
     out = param.copy()

@@ -353,12 +353,21 @@ class HostSim:
         _vec(y, n)[:] = np.where(mk != 0, _vec(x, n) / np.float32(keep), 0)
         return 0
 
+    def npm_dropout_philox(self, x, y, mask, n, keep, seed, offset):
+        keep_mask = O.dropout_philox_mask(int(n), float(keep), int(seed), int(offset))
+        np.ctypeslib.as_array((C.c_ubyte * int(n)).from_address(_addr(mask)))[:] = keep_mask
+        _vec(y, n)[:] = np.where(keep_mask, _vec(x, n) * (np.float32(1.0) / np.float32(keep)), 0)
+        return 0
+
     def npm_set_math(self, mode):
         self.math = int(mode)
         return 0
 
     def npm_get_math(self):
         return getattr(self, 'math', 0)
+
+    def npm_last_math(self):
+        return 0
 
     def npm_set_tuning(self, knob, value):
         return 0

@@ -9,6 +9,16 @@ from oracle import np_oracle as O
 
 pytestmark = pytest.mark.gpu
 
+
+class GradRecorder:
+    """An optimizer that records gradients instead of applying them (parameters stay fixed)."""
+
+    def __init__(self):
+        self.grads = {}
+
+    def update(self, obj, attribute, gradient):
+        self.grads[(type(obj).__name__, attribute, id(obj))] = gradient
+
 _MAP = dict(att_wq=('_self_attention', '_wq'), att_wk=('_self_attention', '_wk'),
             att_wv=('_self_attention', '_wv'), att_wo=('_self_attention', '_wo'),
             att_bq=('_self_attention', '_bq'), att_bk=('_self_attention', '_bk'),
@@ -149,6 +159,44 @@ def test_decoder_golden(npm, name, math_mode):
     assert_close(dkv, g['dkv'], tol=1e-4)
     for k, (path, attr) in _DEC.items():
         assert_close(getattr(_sub(dec, path), attr), g[k + '__1'], tol=1e-4, what=k)
+
+
+@pytest.mark.parametrize('norm_first', [True, False])
+def test_decoder_fused_equals_unfused(npm, norm_first):
+    """The fused decoder composition (residuals and the dkey + dvalue / dq + dk + dv sums in GEMM epilogues and the
+    LayerNorm backward, reference transformer.py:120-203) against the literal composition from standalone kernels,
+    at O(1) activations (the golden fixture's unscaled weights saturate the softmaxes)."""
+    from np_modeling_amd import parallel
+    D = npm.device
+    rng = np.random.default_rng(4)
+    np.random.seed(7)
+    dec = npm.layers.TransformerDecoder(num_heads=4, hidden_units=96, norm_first=norm_first)
+    q = rng.standard_normal([3, 20, 64]).astype(np.float32)
+    kv = rng.standard_normal([3, 37, 64]).astype(np.float32)
+    dy = rng.standard_normal([3, 20, 64]).astype(np.float32)
+    dec(q, kv)
+    for path, attrs in (('_self_attention', ('_wq', '_wk', '_wv', '_wo')), ('_cross_attention', ('_wq', '_wk', '_wv', '_wo')),
+                        ('_dense1._linear', ('_w',)), ('_dense2', ('_w',))):
+        for attr in attrs:
+            arr = getattr(_sub(dec, path), attr)
+            arr.set(np.asarray(arr) / np.float32(8.0))
+    out = np.asarray(dec(q, kv))
+    r1 = GradRecorder()
+    dq1, dkv1 = (np.asarray(g) for g in dec(dy, backprop=True, optimizer_=r1))
+    ref = np.asarray(dec._forward_unfused(D.as_device(q), D.as_device(kv)))
+    assert_close(out, ref, tol=3e-6)
+    r2 = GradRecorder()
+    with parallel.grad_scope(0) as scope:
+        dq2, dkv2 = (np.asarray(g) for g in dec._backward_unfused(D.as_device(dy), r2, scope))
+    assert_close(dq1, dq2, tol=1e-5)
+    assert_close(dkv1, dkv2, tol=1e-5)
+    assert len(r1.grads) == 26 and r1.grads.keys() == r2.grads.keys()
+    for key in r1.grads:
+        a, b = np.asarray(r1.grads[key]), np.asarray(r2.grads[key])
+        if key[1] == '_bk':      # exactly zero in real arithmetic (rows of datt sum to 0): rounding noise in both
+            assert np.abs(a).max() < 1e-4 and np.abs(b).max() < 1e-4
+            continue
+        assert_close(a, b, tol=1e-5, what=str(key[:2]))
 
 
 def test_losses_on_device(npm):

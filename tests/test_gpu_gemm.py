@@ -347,6 +347,27 @@ def test_math_mode_api(D):
     assert npm.get_math() == 'f32'
 
 
+def test_last_math_reports_what_ran(D, math_mode):
+    """npm_get_math() is the mode requested; npm_last_math() the one the last launch ran: the split-bf16 modes exist
+    on the LDS-DMA pipeline only, every other launch runs (and reports) the exact-f32 MFMA."""
+    import np_modeling_amd as npm
+    rng = np.random.default_rng(1)
+
+    def run(m, n, k, ld_pad=0, **kw):
+        a = D.from_host(rng.standard_normal((m, k + ld_pad)).astype(np.float32))
+        b = D.from_host(rng.standard_normal((k, n)).astype(np.float32))
+        c = D.empty([m, n])
+        D.gemm(m, n, k, D.Mat(a, k + ld_pad), D.Mat(b, n), D.Mat(c, n), **kw)
+        return npm.last_math()
+
+    assert npm.get_math() == math_mode
+    assert run(256, 256, 64) == math_mode                      # aligned, K % 16 == 0: the DMA pipeline
+    assert run(256, 256, 72) == 'f32'                          # K % 16 != 0: register-staged fallback
+    assert run(130, 129, 64, ld_pad=1) == 'f32'                # rows not 16-byte aligned
+    assert run(256, 256, 64, colsum_out=D.empty([256])) == 'f32'      # column sums in the epilogue
+    assert run(256, 256, 64) == math_mode
+
+
 def test_bias_gradient_arguments(D):
     from np_modeling_amd import _C
     a, b, c, s = D.zeros([64, 64]), D.zeros([64, 64]), D.empty([64, 64]), D.empty([64])

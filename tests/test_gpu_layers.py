@@ -204,6 +204,78 @@ def test_dropout_identity_and_mask(npm):
     np.testing.assert_allclose(np.asarray(d.backward(xs)), np.where(mask, xs / 0.5, 0.0), rtol=1e-6)
 
 
+@pytest.mark.parametrize('shape,p', [([128, 32], 0.5), ([7, 13, 5], 0.1), ([1000003], 0.9), ([3], 0.25)])
+def test_dropout_device_rng(npm, shape, p):
+    """Masks drawn on the device (Philox4x32-10): bit-equal to the oracle's restatement of the generator (itself pinned by
+    the published known-answer vectors), `_mask` readable like the reference's (normalizations_test.py:15-30),
+    backward applies the same mask, successive calls draw independent masks, a seed reproduces a run."""
+    L = npm.layers
+    keep = 1 - p
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(shape).astype(np.float32)
+    try:
+        npm.set_dropout_rng('device', seed=0x1234567811223344)
+        d = L.DropOut(p)
+        y = np.asarray(d(x))
+        want_mask = O.dropout_philox_mask(x.size, keep, 0x1234567811223344, 0).reshape(shape)
+        np.testing.assert_array_equal(d._mask != 0, want_mask)
+        np.testing.assert_array_equal(y, np.where(want_mask, x * (np.float32(1) / np.float32(keep)), 0).astype(np.float32))
+        dy = rng.standard_normal(shape).astype(np.float32)
+        np.testing.assert_array_equal(np.asarray(d.backward(dy)),
+                                      np.where(want_mask, dy / np.float32(keep), 0).astype(np.float32))
+        y2 = np.asarray(d(x))                                    # next call: next offset
+        np.testing.assert_array_equal(d._mask != 0, O.dropout_philox_mask(x.size, keep, 0x1234567811223344, 1).reshape(shape))
+        npm.set_dropout_rng('device', seed=0x1234567811223344)   # same seed: same run
+        np.testing.assert_array_equal(np.asarray(L.DropOut(p)(x)), y)
+        if x.size > 1000:
+            assert abs((d._mask != 0).mean() - keep) < 0.01 and not np.array_equal(y, y2)
+    finally:
+        npm.set_dropout_rng('host')
+    np.random.seed(3)                                            # back on the host generator
+    h = L.DropOut(p)
+    h(x)
+    np.random.seed(3)
+    np.testing.assert_array_equal(h._mask, np.random.binomial(n=1, p=keep, size=x.size).reshape(shape))
+
+
+def test_encoder_with_device_dropout(npm):
+    """drop_rate > 0 inside the encoder takes the literal (unfused) composition; with device-drawn masks the step
+    equals the oracle's encoder evaluated with those very masks."""
+    rng = np.random.default_rng(2)
+    x = rng.standard_normal([2, 12, 32]).astype(np.float32)
+    dy = rng.standard_normal([2, 12, 32]).astype(np.float32)
+    try:
+        npm.set_dropout_rng('device', seed=99)
+        np.random.seed(0)
+        enc = npm.layers.TransformerEncoder(num_heads=2, hidden_units=48, norm_first=True, drop_rate=0.2)
+        out = np.asarray(enc(x))
+        dx = np.asarray(enc(dy, backprop=True, learning_rate=0.0))
+        m1, m2 = enc._dropout1._mask != 0, enc._dropout2._mask != 0
+        assert m1.shape == (2, 12, 32) and m2.shape == (24, 32) and 0.6 < m1.mean() < 0.95
+    finally:
+        npm.set_dropout_rng('host')
+    # the same computation with dropout off and the masks applied by hand around the norm inputs (pre-norm: x -> drop -> norm)
+    p = {}
+    att = enc._self_attention
+    for n in O.MHA_PARAM_NAMES:
+        p['att_' + n] = np.asarray(getattr(att, '_' + n)).astype(np.float64)
+    for tag, norm in (('n1', enc._norm1), ('n2', enc._norm2)):
+        p[tag + '_gamma'], p[tag + '_beta'] = (np.asarray(getattr(norm, a)).astype(np.float64) for a in ('_gamma', '_beta'))
+    p['d1_w'], p['d1_b'] = (np.asarray(getattr(enc._dense1.linear, a)).astype(np.float64) for a in ('_w', '_b'))
+    p['d2_w'], p['d2_b'] = (np.asarray(getattr(enc._dense2, a)).astype(np.float64) for a in ('_w', '_b'))
+    x64 = x.astype(np.float64)
+    h1 = O.dropout_apply(x64, m1, 0.8)
+    z1, c1 = O.layernorm_fwd(h1, p['n1_gamma'], p['n1_beta'], 1e-3)
+    a_out, _ = O.mha_fwd({n: p['att_' + n] for n in O.MHA_PARAM_NAMES}, z1)
+    s1 = (a_out + x64).reshape(24, 32)
+    h2 = O.dropout_apply(s1, m2, 0.8)
+    z2, _ = O.layernorm_fwd(h2, p['n2_gamma'], p['n2_beta'], 1e-3)
+    hid, _ = O.dense_fwd(z2, p['d1_w'], p['d1_b'])
+    want = (O.linear_fwd(hid, p['d2_w'], p['d2_b']) + s1).reshape(2, 12, 32)
+    assert_close(out, want, tol=1e-5)
+    assert np.isfinite(dx).all()
+
+
 # ---- MultiHeadAttention ------------------------------------------------------------------------
 _MHA = ['wq', 'wk', 'wv', 'wo', 'bq', 'bk', 'bv', 'bo']
 

@@ -84,6 +84,26 @@ def test_encoder_composition_on_simulator(npm, name):
     assert_close(enc._norm1._gamma, g['n1_gamma__1'], tol=1e-5)
 
 
+@pytest.mark.parametrize('name', ['decoder_prenorm', 'decoder_postnorm'])
+def test_decoder_fused_composition_on_simulator(npm, name):
+    """The fused decoder composition (seeded draw order, residual / sum epilogues, the (dq, dkv) tuple) against the
+    reference's own outputs (reference transformer.py:95-203, transformer_test.py:159-219)."""
+    g = load_golden(name)
+    np.random.seed(0)
+    dec = npm.layers.TransformerDecoder(num_heads=int(g['heads']), hidden_units=int(g['hidden']),
+                                        norm_first=bool(g['norm_first']))
+    out = dec(rand(g['q'].shape), rand(g['kv'].shape))
+    assert dec._fusable()
+    np.testing.assert_array_equal(np.asarray(dec._cross_attention._wk), g['ca_wk__0'])      # reference draw order
+    assert_close(out, g['out'], tol=1e-4)
+    dq, dkv = dec(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dq, g['dq'], tol=1e-4)
+    assert_close(dkv, g['dkv'], tol=1e-4)
+    assert_close(dec._dense2.w, g['d2_w__1'], tol=1e-4)
+    assert_close(dec._cross_attention._wv, g['ca_wv__1'], tol=1e-4)
+    assert_close(dec._norm3._gamma, g['n3_gamma__1'], tol=1e-4)
+
+
 def test_weights_rebound_between_forward_and_backward(npm):
     """The packed q/k/v projection must not assume the parameters are still adjacent in the backward:
     bench.py (and weight binders) rebind them after the first forward."""
@@ -387,3 +407,27 @@ def test_mha_fused_core_path_on_simulator(npm, masked):
         assert_close(np.asarray(dk) + np.asarray(dv), wk_ + wv_, tol=1e-6)
         for n in names:
             assert_close(getattr(layer, '_' + n), p[n] - 0.1 * grads[n], tol=1e-6, what=n)
+
+
+def test_dropout_device_rng_plumbing(npm):
+    """set_dropout_rng('device'): the mask comes from npm_dropout_philox, `_mask` is read back lazily, successive
+    calls advance the offset, 'host' restores the reference's np.random.binomial draw."""
+    from oracle import np_oracle as O
+    x = np.arange(24, dtype=np.float32).reshape(4, 6) + 1
+    try:
+        npm.set_dropout_rng('device', seed=5)
+        d = npm.layers.DropOut(0.25)
+        y = np.asarray(d(x))
+        want = O.dropout_philox_mask(24, 0.75, 5, 0).reshape(4, 6)
+        np.testing.assert_array_equal(d._mask != 0, want)
+        np.testing.assert_allclose(y, np.where(want, x / 0.75, 0), rtol=1e-6)
+        np.testing.assert_allclose(np.asarray(d.backward(x)), np.where(want, x / 0.75, 0), rtol=1e-6)
+        d(x)
+        np.testing.assert_array_equal(d._mask != 0, O.dropout_philox_mask(24, 0.75, 5, 1).reshape(4, 6))
+    finally:
+        npm.set_dropout_rng('host')
+    np.random.seed(1)
+    h = npm.layers.DropOut(0.25)
+    h(x)
+    np.random.seed(1)
+    np.testing.assert_array_equal(h._mask, np.random.binomial(n=1, p=0.75, size=24).reshape(4, 6))

@@ -224,3 +224,18 @@ def test_attention_core_restatements_agree():
             ops[which][idx] += delta
             return (O.attention_core_fwd(*ops, scale)[0] * dctx).sum()
         np.testing.assert_allclose((loss(eps) - loss(-eps)) / (2 * eps), grad[idx], rtol=1e-5, atol=1e-8)
+
+
+def test_philox_known_answers():
+    """Philox4x32-10 known-answer vectors published with the generator (Random123 kat_vectors): they pin the oracle's
+    restatement, which in turn pins the device kernel's masks bit for bit (tests/test_gpu_rowops.py)."""
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff, 0xffffffff), (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for counter, key, want in kat:
+        got = O.philox4x32_10(np.array([counter], dtype=np.uint32), key)[0]
+        assert tuple(int(v) for v in got) == want
+    mask = O.dropout_philox_mask(100003, 0.75, seed=1234, offset=7)
+    assert mask.shape == (100003,) and abs(mask.mean() - 0.75) < 0.01
+    assert not np.array_equal(mask, O.dropout_philox_mask(100003, 0.75, seed=1234, offset=8))
+    assert O.dropout_philox_mask(10, 1.0, 0, 0).all()
