@@ -94,10 +94,47 @@ def cpu_baseline(args, params):
             p[k] = O.sgd_step(p[k], grads[k], 1e-4)
         times.append(time.perf_counter() - t0)
     best = min(times)
-    return dict(value=b / best, unit='samples/s', cores=os.cpu_count(), kind='port',
-                sample=f'NumPy oracle (closed-form restatement, OpenBLAS) encoder fwd+bwd+SGD, batch {b} x seq {args.seq} '
-                       f'x d {args.features}, U={args.hidden}, best of {args.cpu_steps} steps ({best:.2f} s/step); '
-                       'the reference-verbatim Jacobian form needs TBs at this width (BASELINE.md)')
+    out = dict(value=b / best, unit='samples/s', cores=os.cpu_count(), kind='port',
+               sample=f'NumPy oracle (closed-form restatement, OpenBLAS) encoder fwd+bwd+SGD, batch {b} x seq {args.seq} '
+                      f'x d {args.features}, U={args.hidden}, best of {args.cpu_steps} steps ({best:.2f} s/step)')
+    if args.cpu_verbatim_seq > 0:
+        # Line (1) of BASELINE.md section 3: the reference's OWN formulation (explicit [rows, d, d] LayerNorm and
+        # [rows, n, n] softmax Jacobians in fp64, np.einsum contractions: single-threaded C loops, no BLAS), restated
+        # verbatim by the oracle.  Its temporaries grow with seq^2 and d^2 (TBs at the full shape), so the sample is
+        # ONE sequence of `cpu_verbatim_seq` tokens at the full width; the rate is quoted in tokens/s and, divided by
+        # seq, as the samples/s a full-length sample could at best reach.
+        sv = args.cpu_verbatim_seq
+        qv = rng.standard_normal([1, sv, args.features], dtype=np.float32)
+        dv = rng.standard_normal([1, sv, args.features], dtype=np.float32) * np.float32(0.01)
+        t0 = time.perf_counter()
+        _, cache = O.encoder_fwd(params, qv, True, verbatim=True)
+        _, grads = O.encoder_bwd(params, cache, dv, True, verbatim=True)
+        for k in params:
+            O.sgd_step(params[k], grads[k], 1e-4)
+        tv = time.perf_counter() - t0
+        out['reference_verbatim'] = dict(
+            value=sv / tv / args.seq, unit='samples/s', tokens_per_s=sv / tv, cores=1, kind='port',
+            sample=f'reference-verbatim formulation (Jacobian einsums, fp64 temporaries) encoder fwd+bwd+SGD, 1 x seq {sv} '
+                   f'x d {args.features}, U={args.hidden}, one step ({tv:.1f} s); samples/s = tokens/s / {args.seq} (an upper '
+                   'bound: attention and the softmax Jacobian grow faster than linearly in seq)')
+    return out
+
+
+def alt_roofline(timer):
+    """Kernel-level roofline of the split-bf16 GEMM family against the bf16 MFMA peak: every fp32 product is executed as
+    six v_mfma_f32_32x32x16_bf16, so the pipe executes 6x the algorithmic fp32 FLOPs."""
+    if timer is None:
+        return None
+    gemm = {k: v for k, v in timer.summary().items() if k.startswith(MFMA_BOUND)}
+    ms, flops = sum(v['ms'] for v in gemm.values()), sum(v['flops'] for v in gemm.values())
+    launches = sum(v['launches'] for v in gemm.values())
+    if ms <= 0:
+        return None
+    executed = 6 * flops / (ms * 1e-3) / 1e12
+    return {'kernel': 'sgemm_glds_kernel<..., MATH = 2> (six v_mfma_f32_32x32x16_bf16 per fp32 product; attention composed from these GEMMs)',
+            'bound': 'mfma', 'achieved': executed, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA work executed)',
+            'frac': executed / BF16_MFMA_PEAK_TFLOPS, 'fp32_equivalent_tflops': flops / (ms * 1e-3) / 1e12,
+            'launches': launches, 'avg_launch_ms': ms / max(launches, 1), 'traffic': None}
 
 
 def load_pmc_traffic(args):
@@ -125,6 +162,7 @@ def main():
     ap.add_argument('--hidden', type=int, default=4096)
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
+    ap.add_argument('--cpu-verbatim-seq', type=int, default=128, help='tokens of the reference-verbatim CPU sample (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16x3_fast'],
@@ -250,6 +288,9 @@ def main():
         D.synchronize()
         if comm.active:
             comm.barrier()
+        alt_timer = None if args.no_kernel_timer else D.KernelTimer()
+        if alt_timer is not None:
+            alt_timer.__enter__()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
@@ -257,6 +298,8 @@ def main():
         if comm.active:
             comm.barrier()
         alt = time.perf_counter() - t0
+        if alt_timer is not None:
+            alt_timer.__exit__(None, None, None)
         if comm.active:
             alt = comm.allreduce_scalar(alt, parallel.MAX)
         npm.set_math('f32')
@@ -266,6 +309,7 @@ def main():
             'steps': args.steps, 'step_tflops_per_gpu': alt_value / world * fps / 1e12,
             'step_frac_of_fp32_mfma_peak': alt_value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS,
             'executed_bf16_mfma_frac_of_bf16_peak': 6 * alt_value / world * fps / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+            'roofline': alt_roofline(alt_timer),
             'note': 'same workload and timing protocol with npm_set_math(NPM_MATH_BF16X3): fp32 inputs/outputs/accumulators, '
                     'each product formed from three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16); '
                     'rms error vs fp64 at or below the exact-f32 MFMA path (profiles/r01_math_error.log). '

@@ -453,7 +453,7 @@ __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
                      const float *__restrict__ rstd, const float *__restrict__ gamma,
                      const float *__restrict__ residual, long rows, int d, float *__restrict__ dx,
-                     float *__restrict__ part_gamma, float *__restrict__ part_beta) {
+                     float *__restrict__ part) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = d >> 2;
     float4 gm[VPL], dg[VPL], db[VPL];
@@ -500,14 +500,31 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
             }
         }
     }
-    // one partial row per wave; a column sum over all wave partials finishes dgamma/dbeta
-    const long prow = (long)blockIdx.x * ROWS_PER_BLOCK + wave;
+    // One partial row per BLOCK, dgamma and dbeta side by side ([blocks][2 d]): the waves' partials meet in LDS and
+    // wave 0 adds them in wave order (fixed: reproducible); one column sum over the block partials finishes both.
+    __shared__ float4 red[3][VPL * WAVE];
+    float4 *prow = reinterpret_cast<float4 *>(part + (long)blockIdx.x * 2 * d);
 #pragma unroll
-    for (int j = 0; j < VPL; ++j) {
-        const int c = lane + WAVE * j;
-        if (c < nvec) {
-            reinterpret_cast<float4 *>(part_gamma + prow * d)[c] = dg[j];
-            reinterpret_cast<float4 *>(part_beta + prow * d)[c] = db[j];
+    for (int pass = 0; pass < 2; ++pass) {
+        float4 (&mine)[VPL] = pass == 0 ? dg : db;
+        if (pass) __syncthreads();
+        if (wave > 0) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) red[wave - 1][lane + WAVE * j] = mine[j];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int c = lane + WAVE * j;
+                float4 t = mine[j];
+#pragma unroll
+                for (int w = 0; w < 3; ++w) {
+                    const float4 o = red[w][c];
+                    t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
+                }
+                if (c < nvec) prow[pass * nvec + c] = t;
+            }
         }
     }
 }
@@ -704,11 +721,10 @@ int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const 
         const long row_blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
         const int grid = (int)std::min<long>(row_blocks, (long)g_ln_bwd_blocks_per_cu * npm::ctx().num_cus);
         npm::Scratch part;
-        const long prow = (long)grid * ROWS_PER_BLOCK;
-        int rc = part.alloc(sizeof(float) * 2 * (size_t)prow * d);
+        int rc = part.alloc(sizeof(float) * 2 * (size_t)grid * d);
         if (rc) return rc;
-        float *pg = (float *)part.ptr, *pb = pg + (size_t)prow * d;
-#define NPM_LNB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pg, pb)
+        float *pp = (float *)part.ptr;                     // [grid][2 d]: dgamma partials | dbeta partials
+#define NPM_LNB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp)
         if (d <= 256) NPM_LNB(1);
         else if (d <= 512) NPM_LNB(2);
         else if (d <= 1024) NPM_LNB(4);
@@ -716,9 +732,10 @@ int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const 
         else NPM_LNB(16);
 #undef NPM_LNB
         NPM_CHECK_LAUNCH();
-        rc = colsum_impl(pg, dgamma, prow, d, d);
+        if (dbeta == dgamma + d) return colsum_impl(pp, dgamma, grid, 2 * d, 2 * d);      // adjacent outputs (the gradient bucket): one pass
+        rc = colsum_impl(pp, dgamma, grid, d, 2 * d);
         if (rc) return rc;
-        return colsum_impl(pb, dbeta, prow, d, d);
+        return colsum_impl(pp + d, dbeta, grid, d, 2 * d);
     }
     NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
     npm::Scratch tmp;

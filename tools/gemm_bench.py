@@ -59,6 +59,11 @@ def main():
         'pv_NN  2048x(512x128x512)': (2.0 * B * H * S * S * Dk, lambda: D.gemm(S, Dk, S, Mat(scores, S, H * S * S, S * S), Mat(x, F, S * F, Dk), Mat(out_f, F, S * F, Dk), batch=(B, H))),
         'dv_TN  2048x(512x128x512)': (2.0 * B * H * S * S * Dk, lambda: D.gemm(S, Dk, S, Mat(scores, S, H * S * S, S * S), Mat(x, F, S * F, Dk), Mat(out_f, F, S * F, Dk), trans_a=True, batch=(B, H))),
     }
+    n2 = 4096            # BASELINE configs[1]: Dense 4096 -> 4096, batch 4096 (one generation of 1024 tiles)
+    a2, b2, c2 = buf(n2 * n2), buf(n2 * n2), D.empty([n2 * n2])
+    shapes['c2_fwd_NN M=4096 N=4096 K=4096'] = (2.0 * n2 ** 3, lambda: D.gemm(n2, n2, n2, Mat(a2, n2), Mat(b2, n2), Mat(c2, n2)))
+    shapes['c2_dx_NT  M=4096 N=4096 K=4096'] = (2.0 * n2 ** 3, lambda: D.gemm(n2, n2, n2, Mat(a2, n2), Mat(b2, n2), Mat(c2, n2), trans_b=True))
+    shapes['c2_dw_TN  M=4096 N=4096 K=4096'] = (2.0 * n2 ** 3, lambda: D.gemm(n2, n2, n2, Mat(a2, n2), Mat(b2, n2), Mat(c2, n2), trans_a=True))
     total_ms, total_flops = 0.0, 0.0
     for _ in range(3):           # clocks up before the first measured shape
         list(shapes.values())[4][1]()
