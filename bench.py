@@ -162,7 +162,7 @@ def main():
     ap.add_argument('--hidden', type=int, default=4096)
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=3)
-    ap.add_argument('--cpu-verbatim-seq', type=int, default=128, help='tokens of the reference-verbatim CPU sample (0 = skip)')
+    ap.add_argument('--cpu-verbatim-seq', type=int, default=256, help='tokens of the reference-verbatim CPU sample (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16x3_fast'],
