@@ -257,15 +257,15 @@ def main():
 
     if timer is not None:
         summary = timer.summary()
-        gemm = {k: v for k, v in summary.items() if k.startswith(MFMA_BOUND)}
+        gemm = {k: v for k, v in summary.items() if k.startswith('sgemm_')}             # the dominant kernel
+        attn = {k: v for k, v in summary.items() if k.startswith('mha_core_')}
         g_ms = sum(v['ms'] for v in gemm.values())
         g_flops = sum(v['flops'] for v in gemm.values())
         g_launches = sum(v['launches'] for v in gemm.values())
         achieved = g_flops / (g_ms * 1e-3) / 1e12 if g_ms > 0 else 0.0
         traffic, traffic_src = load_pmc_traffic(args)
         result['roofline'] = {
-            'kernel': ('fp32 v_mfma_f32_32x32x2_f32 family: sgemm_glds_kernel (LDS-DMA pipeline, NN/NT/TN) and the fused attention core '
-                       'mha_fwd_kernel / mha_bwd_kernel (algorithmic FLOPs: 2 + 4 products; a recomputed q.k is not counted)' if args.math == 'f32' else
+            'kernel': ('sgemm_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family, LDS-DMA pipeline: NN/NT/TN)' if args.math == 'f32' else
                        f'sgemm_glds_kernel ({args.math}: six v_mfma_f32_32x32x16_bf16 per fp32 product; achieved counts fp32-equivalent '
                        'FLOPs against the f32 MFMA peak, the bf16 pipe executes 6x that)'),
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
@@ -276,6 +276,11 @@ def main():
             'share_of_step_time': g_ms / (1e3 * elapsed) if elapsed > 0 else None,
             'by_layout': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],
                               'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12} for k, v in sorted(gemm.items())},
+            'other_mfma_kernels': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],
+                                       'tflops': v['flops'] / (v['ms'] * 1e-3) / 1e12,
+                                       'frac': v['flops'] / (v['ms'] * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+                                       'share_of_step_time': v['ms'] / (1e3 * elapsed)}
+                                   for k, v in sorted(attn.items())},       # fused attention core: 2 + 4 algorithmic products
             'hbm_kernels': {k: {'launches': v['launches'], 'avg_ms': v['ms'] / v['launches'],
                                 'GBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in sorted(summary.items()) if not k.startswith(MFMA_BOUND) and v['ms'] > 0},

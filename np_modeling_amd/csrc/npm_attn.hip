@@ -229,6 +229,9 @@ mha_fwd_kernel(const MhaArgs p) {
     }
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                                // tile t has landed; nobody still reads the stage refilled next
+        long long *tr = (p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
+        if (p.trace && tid == 0 && t == (nt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime(); FENCE(); }
+        STAMP(0);
         if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
         const float *sK = smem + (t & 1) * TILE, *sV = smem + (2 + (t & 1)) * TILE;
 
@@ -249,6 +252,7 @@ mha_fwd_kernel(const MhaArgs p) {
             S = MFMA(fk[g & 1].w, qf[g].w, S);
             FENCE();
         }
+        STAMP(1);
         const int kv0 = 32 * t + 4 * half;              // register r holds key kv0 + (r & 3) + 8 (r >> 2)
         if (32 * t + 32 > p.seq_kv) {
 #pragma unroll
@@ -272,29 +276,35 @@ mha_fwd_kernel(const MhaArgs p) {
                         if (kv + e < p.seq_kv) srow[kv + e] = S[4 * g4 + e];
             }
         }
-        // ---- online softmax in the exp2 domain: the statistics of query `qrow` live on its two lanes
+        // ---- online softmax in the exp2 domain: the statistics of query `qrow` live on its two lanes.  The running
+        //      maximum is only a reference point: it moves (and the accumulators are rescaled) when some row of the wave
+        //      would otherwise exceed it by more than 2^RESCALE -- a few times per block instead of almost every tile
+        //      (the rescale is 32 packed multiplies that issue beside nothing).  Probabilities stay below 2^RESCALE.
+        constexpr float RESCALE = 10.f;
         float tmax = S[0];
 #pragma unroll
         for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, S[r]);
-        tmax = fmaxf(tmax, xhalf(tmax));
-        const float m_new = fmaxf(m, tmax * c);
-        const float alpha = fast_exp2(m - m_new);
+        tmax = fmaxf(tmax, xhalf(tmax)) * c;
+        float m_new = m;
+        if (__builtin_amdgcn_ballot_w64(tmax > m + RESCALE) != 0) {       // first tile: m = -inf
+            m_new = fmaxf(m, tmax);
+            const float alpha = fast_exp2(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int t2 = 0; t2 < DT; ++t2)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) O[t2][e] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             S[r] = fast_exp2(fmaf(S[r], c, -m_new));
             psum += S[r];
         }
-        psum += xhalf(psum);
-        l = fmaf(l, alpha, psum);
-        if (__builtin_amdgcn_ballot_w64(m_new != m) != 0) {      // some row's maximum moved: rescale the accumulators
-#pragma unroll
-            for (int t2 = 0; t2 < DT; ++t2)
-#pragma unroll
-                for (int e = 0; e < 16; ++e) O[t2][e] *= alpha;
-        }
+        l += psum + xhalf(psum);
         m = m_new;
         FENCE();
+        STAMP(2);
         // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]: 16 steps (one key row each) of (1 vector read, DT MFMAs);
         //      tile t2 row `lane` is head dimension VEC lane + t2
 #pragma unroll
@@ -305,6 +315,7 @@ mha_fwd_kernel(const MhaArgs p) {
             for (int t2 = 0; t2 < DT; ++t2) O[t2] = MFMA(ev[r & 1][t2], S[r], O[t2]);
             FENCE();
         }
+        STAMP(3);
     }
 
     const float inv = 1.f / l;

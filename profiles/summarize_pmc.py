@@ -33,7 +33,7 @@ def main():
         f, w = fetch[name], write.get(name, [0.0])
         kernels[short] = dict(launches=len(f), fetch_kib_raw_per_launch=sum(f) / len(f), write_kib_per_launch=sum(w) / len(w),
                               bytes_per_launch=(2 * sum(f) / len(f) + sum(w) / len(w)) * 1024)
-    gemm = {k: v for k, v in kernels.items() if k.startswith(('sgemm_', 'mha_fwd', 'mha_bwd'))}      # the MFMA-bound family of bench.py's roofline
+    gemm = {k: v for k, v in kernels.items() if k.startswith('sgemm_')}      # bench.py's roofline kernel
     n = sum(v['launches'] for v in gemm.values())
     family = sum(v['bytes_per_launch'] * v['launches'] for v in gemm.values()) / max(n, 1)
     print(json.dumps(dict(gemm_family_bytes_per_launch=family, gemm_family_launches=n, kernels=kernels,

@@ -228,18 +228,19 @@ def test_layer_fused_core_equals_gemm_composition_and_oracle(npm, heads, feat, s
     kv = rng.standard_normal([3, skv, feat]).astype(np.float32) if cross else None
     dy = rng.standard_normal([3, sq, feat]).astype(np.float32)
     results = []
-    for core in (True, False):
-        D.ATTN_CORE = core
+    saved_default = D.ATTN_SAVE_SCORES
+    for core, save in ((True, True), (True, False), (False, False)):       # fused (scores kept), fused (log-sum-exp only), GEMMs
+        D.ATTN_CORE, D.ATTN_SAVE_SCORES = core, save
         try:
             layer, p = _layer(npm, heads, feat, 3)
             for n in _MHA:
                 setattr(layer, '_' + n, p[n].copy())
             out = np.asarray(layer(query, kv) if cross else layer(query))
-            assert layer._core is core
+            assert layer._core is core and (layer._raw_scores is not None) is (core and save) if core else True
             grads = [np.asarray(g) for g in layer(dy, backprop=True, learning_rate=0.05)]
             results.append((out, grads, {n: np.asarray(getattr(layer, '_' + n)) for n in _MHA}))
         finally:
-            D.ATTN_CORE = True
+            D.ATTN_CORE, D.ATTN_SAVE_SCORES = True, saved_default
     p64 = {n: p[n].astype(np.float64) for n in _MHA}
     want, cache = O.mha_fwd(p64, query.astype(np.float64), None if kv is None else kv.astype(np.float64))
     wg, pg = O.mha_bwd(p64, cache, dy.astype(np.float64))

@@ -22,10 +22,23 @@ dqkv = D.empty([b, s, 3, h, d])
 dq, dk, dv = dqkv, dqkv.flat_view(f, [dqkv.size - f]), dqkv.flat_view(2 * f, [dqkv.size - 2 * f])
 dims = (b, h, s, s, d)
 scale = 1.0 / np.sqrt(d)
-ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, save_scores='--save-scores' in sys.argv)
+lib = _C.lib()
+save = '--save-scores' in sys.argv
+ftrace = D._Buffer(8 * 16 * b * h * 4)
+for rep in range(3):
+    _C.check(lib.npm_debug_attn_trace(ftrace.ptr))
+    ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, save_scores=save)
+    D.synchronize()
+    _C.check(lib.npm_debug_attn_trace(None))
+fh = np.zeros([b * h * 4, 16], dtype=np.int64)
+_C.check(lib.npm_d2h(fh.ctypes.data, ftrace.ptr, fh.nbytes))
+print('forward, one 32-key tile of one wave (two waves share a SIMD: 128 MFMAs of this wave = 8192 cycles alone, 16384 at half the pipe)')
+for i, n in enumerate(['S^T = K Q^T (+next DMA)', 'online softmax', 'O^T += V^T P^T', 'to next tile start']):
+    col = fh[:, i + 1] - fh[:, i]
+    print(f'{n:26s} {np.median(col):7.0f} {np.percentile(col, 10):6.0f} {np.percentile(col, 90):6.0f}')
+print(f'tile total                 {np.median(fh[:, 4] - fh[:, 0]):7.0f}')
 nblocks = b * h
 trace = D._Buffer(8 * 16 * nblocks)
-lib = _C.lib()
 for rep in range(3):
     _C.check(lib.npm_debug_attn_trace(trace.ptr))
     D.mha_core_bwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), ctx, lse, dctx, Mat(dq, 3 * f), Mat(dk, 3 * f), Mat(dv, 3 * f), dims, scale, scores=scores)
