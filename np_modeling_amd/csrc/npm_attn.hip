@@ -779,9 +779,15 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
     MhaArgs a;
     int rc = fill_args(c, true, a);
     if (rc) return rc;
-    if ((long)a.batch * a.heads == 0 || a.seq_q == 0) return NPM_OK;
+    if ((long)a.batch * a.heads == 0) return NPM_OK;
     hipStream_t s = npm::ctx().stream;
-    npm::Scratch ws;                                   // stream-ordered pool: safe to release when this call returns
+    if (a.seq_q == 0) {                                  // no queries: nothing flows back to the keys and values
+        const size_t width = sizeof(float) * (size_t)a.heads * c->head_dim, rows = (size_t)a.batch * a.seq_kv;
+        NPM_HIP(hipMemset2DAsync(a.dk, sizeof(float) * a.dk_pitch, 0, width, rows, s));
+        NPM_HIP(hipMemset2DAsync(a.dv, sizeof(float) * a.dv_pitch, 0, width, rows, s));
+        return NPM_OK;
+    }
+    npm::Scratch ws;                                  // stream-ordered pool: safe to release when this call returns
     const long rows = (long)a.batch * a.seq_q * a.heads;
     rc = ws.alloc(sizeof(float) * (size_t)rows);
     if (rc) return rc;

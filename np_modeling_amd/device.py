@@ -54,6 +54,25 @@ class _Buffer:
             except Exception:       # interpreter shutdown
                 pass
 
+    def __deepcopy__(self, memo):
+        """A block of its own with the same bytes, ONCE per deepcopy (``memo``): everything that shared this block
+        shares the copy.  (The default protocol would duplicate the owner of ``ptr``: two frees of one block.)"""
+        key = ('np_modeling_amd._Buffer', id(self))
+        buf = memo.get(key)
+        if buf is None:
+            buf = _Buffer(self.nbytes)
+            if self.nbytes:
+                _C.check(_C.lib().npm_d2d(buf.ptr, self.ptr, self.nbytes), 'npm_d2d')
+            memo[key] = buf
+            memo[id(buf)] = buf                  # keeps `buf` alive for the duration of the deepcopy
+        return buf
+
+    def __copy__(self):
+        raise TypeError('a device block has one owner: share the _Buffer object or deepcopy it')
+
+    def __reduce__(self):
+        raise TypeError('device memory cannot be pickled: copy the array to the host (numpy()) first')
+
 
 class Scaled:
     """``alpha * array`` kept symbolic so that ``variable -= lr * gradient`` is ONE axpy
@@ -182,14 +201,7 @@ class DeviceArray:
         """Copies the OWNING pool block once per deepcopy (through ``memo``) and rebases this view into the copy:
         views that shared a block still share one afterwards -- the packed q/k/v projection parameters stay
         adjacent, and pointer views used as strided GEMM operands keep everything they address."""
-        key = ('np_modeling_amd._Buffer', id(self._buf))
-        buf = memo.get(key)
-        if buf is None:
-            buf = _Buffer(self._buf.nbytes)
-            if self._buf.nbytes:
-                _C.check(_C.lib().npm_d2d(buf.ptr, self._buf.ptr, self._buf.nbytes), 'npm_d2d')
-            memo[key] = buf
-            memo[id(buf)] = buf                  # keeps `buf` alive for the duration of the deepcopy
+        buf = self._buf.__deepcopy__(memo)
         return DeviceArray(self.shape, buf, buf.ptr + (self.ptr - self._buf.ptr))
 
     def astype(self, dtype, copy=True):
@@ -332,6 +344,12 @@ class ByteBuffer:
     def __init__(self, nbytes: int):
         self._buf = _Buffer(nbytes)
         self.ptr, self.nbytes = self._buf.ptr, int(nbytes)
+
+    def __deepcopy__(self, memo):
+        out = ByteBuffer.__new__(ByteBuffer)
+        out._buf = self._buf.__deepcopy__(memo)
+        out.ptr, out.nbytes = out._buf.ptr, self.nbytes
+        return out
 
 
 def bytes_from_host(value: np.ndarray) -> ByteBuffer:

@@ -279,3 +279,25 @@ def test_layer_masked_attention(npm):
     np.testing.assert_array_equal(np.asarray(layer(query, mask=False)), np.asarray(layer(query)))
     with pytest.raises(AssertionError):
         layer(query, mask=np.ones([b, heads, s + 1, s], dtype=bool))
+
+
+def test_core_bwd_without_queries_zeroes_key_value_grads(npm):
+    """seq_q = 0: no query attends to the keys, so dk = dv = 0 (and nothing else is touched)."""
+    from np_modeling_amd import _C, device as D
+    b, h, skv, d = 2, 3, 40, 16
+    one = D.full([16], 1.0)                                     # valid, never dereferenced: the query side is empty
+    k = D.from_host(np.random.default_rng(0).normal(size=(b, skv, h, d)).astype(np.float32))
+    dk, dv = D.full([b * skv * h * d + 64], 777.0), D.full([b * skv * h * d + 64], 777.0)
+    c = _C.npm_mha_core()
+    c.batch, c.heads, c.seq_q, c.seq_kv, c.head_dim, c.scale = b, h, 0, skv, d, 0.25
+    c.q = c.ctx = c.lse = c.dctx = c.dq = one.ptr
+    c.k = c.v = k.ptr
+    c.q_pitch = c.k_pitch = c.v_pitch = c.ctx_pitch = c.dctx_pitch = c.dq_pitch = c.dk_pitch = c.dv_pitch = h * d
+    c.dk, c.dv = dk.ptr, dv.ptr
+    _C.check(_C.lib().npm_mha_core_fwd(C.byref(c)), 'npm_mha_core_fwd')
+    _C.check(_C.lib().npm_mha_core_bwd(C.byref(c)), 'npm_mha_core_bwd')
+    for g in (dk, dv):
+        raw = g.numpy()
+        np.testing.assert_array_equal(raw[:b * skv * h * d], 0.0)
+        np.testing.assert_array_equal(raw[b * skv * h * d:], 777.0)
+    np.testing.assert_array_equal(one.numpy(), 1.0)

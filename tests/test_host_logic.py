@@ -363,6 +363,48 @@ def test_deepcopy_after_packed_forward(npm):
                                   np.asarray(enc(dy, backprop=True, learning_rate=0.1)))
 
 
+def test_deepcopy_owns_its_device_blocks(npm):
+    """Every holder of device memory copies the BLOCK, never just its owner object (two owners = two frees of one
+    pool block): dropout masks (p > 0, host- and device-drawn), an encoder with dropout, raw blocks; shallow copies
+    and pickling of a block are refused."""
+    import copy
+    import pickle
+    D = npm.device
+    x, dy = rand([2, 6, 8]), rand([2, 6, 8])
+    np.random.seed(3)
+    d = npm.layers.DropOut(0.5)
+    d(x)
+    twin = copy.deepcopy(d)
+    assert twin._mask_dev.ptr != d._mask_dev.ptr and twin._mask_dev._buf is not d._mask_dev._buf
+    np.testing.assert_array_equal(np.asarray(twin.backward(dy)), np.asarray(d.backward(dy)))
+    np.testing.assert_array_equal(twin._mask, d._mask)
+    del twin                                          # returns ITS block only; d still works
+    np.testing.assert_array_equal(np.asarray(d.backward(dy)), np.where(d._mask, dy / 0.5, 0).astype(np.float32))
+    try:
+        npm.set_dropout_rng('device', seed=1)
+        e = npm.layers.DropOut(0.5)
+        e(x)
+        twin = copy.deepcopy(e)
+        np.testing.assert_array_equal(twin._mask, e._mask)
+        np.testing.assert_array_equal(np.asarray(twin.backward(dy)), np.asarray(e.backward(dy)))
+    finally:
+        npm.set_dropout_rng('host')
+    np.random.seed(0)
+    enc = npm.layers.TransformerEncoder(num_heads=2, hidden_units=12, norm_first=True, drop_rate=0.25)
+    enc(x)
+    twin = copy.deepcopy(enc)
+    np.testing.assert_array_equal(np.asarray(twin(dy, backprop=True, learning_rate=0.1)),
+                                  np.asarray(enc(dy, backprop=True, learning_rate=0.1)))
+    a = D.from_host(x)
+    with pytest.raises(TypeError):
+        copy.copy(a._buf)
+    with pytest.raises(TypeError):
+        pickle.dumps(a._buf)
+    views = copy.deepcopy([a, a.flat_view(8, [4])])   # one memo: the two views still share one (new) block
+    assert views[0]._buf is views[1]._buf and views[0]._buf is not a._buf
+    np.testing.assert_array_equal(np.asarray(views[1]), x.reshape(-1)[8:12])
+
+
 def test_loss_reads_refilled_targets(npm):
     """A caller may refill the SAME host array between steps (targets[:] = next_batch); the reference reads it
     afresh at every forward (loss.py:21-25)."""
