@@ -172,6 +172,8 @@ mha_fwd_kernel(const MhaArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long *const blk_tr = (p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;   // block-level stamps 9..13
+    if (blk_tr) blk_tr[9] = __builtin_amdgcn_s_memtime();
     const int l32 = lane & 31, half = lane >> 5;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
@@ -227,6 +229,7 @@ mha_fwd_kernel(const MhaArgs p) {
     if (p.stagger && ((blockIdx.x >> 8) & 1)) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
+    if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nt; ++t) {
         __syncthreads();                                // tile t has landed; nobody still reads the stage refilled next
         long long *tr = (p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
@@ -317,6 +320,7 @@ mha_fwd_kernel(const MhaArgs p) {
         }
         STAMP(3);
     }
+    if (blk_tr) blk_tr[12] = __builtin_amdgcn_s_memtime();
 
     const float inv = 1.f / l;
     if (half == 0 && qok) p.lse[(long)bh * p.seq_q + qrow] = (m + __builtin_amdgcn_logf(l)) * LN2;       // v_log_f32 is log2
@@ -333,6 +337,10 @@ mha_fwd_kernel(const MhaArgs p) {
                 for (int t2 = 0; t2 < DT; ++t2)
                     __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(O[t2][r] * inv), rsrcC, off == OOB ? OOB : off + 4 * t2, 0, 0);
         }
+    }
+    if (blk_tr) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        blk_tr[13] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -360,6 +368,8 @@ mha_bwd_kernel(const MhaArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    long long *const blk_tr = (p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;   // block-level stamps 9..13
+    if (blk_tr) blk_tr[9] = __builtin_amdgcn_s_memtime();
     const int l32 = lane & 31, half = lane >> 5;
     const int dcol = D < 32 ? (l32 & (D - 1)) : l32;
     const int bh = blockIdx.x;
@@ -451,6 +461,7 @@ mha_bwd_kernel(const MhaArgs p) {
     // Row terms of the next tile (one query per lane), fetched one tile ahead -- across the seams too
     float lse_n = l32 < p.seq_q ? lse[l32] * LOG2E : 0.f, dlt_n = l32 < p.seq_q ? dlt[l32] : 0.f;
 
+    if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int kb = 0; kb < nkb; ++kb) {
         const int kvrow = kb * 128 + kvl;
         const bool kvok = kvrow < p.seq_kv;
@@ -636,6 +647,7 @@ mha_bwd_kernel(const MhaArgs p) {
             STAMP(7);
             FENCE();
         }
+        if (blk_tr && kb == 0) blk_tr[11] = __builtin_amdgcn_s_memtime();
         if (SEAM_STORES == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // this block's dK and dV rows: lane = key; register r of the DT tiles together is VEC adjacent head dimensions
 #pragma unroll
@@ -656,6 +668,11 @@ mha_bwd_kernel(const MhaArgs p) {
                 }
             }
         }
+    }
+    if (blk_tr) {
+        blk_tr[12] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        blk_tr[13] = __builtin_amdgcn_s_memtime();
     }
 }
 

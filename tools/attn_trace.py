@@ -37,6 +37,8 @@ for i, n in enumerate(['S^T = K Q^T (+next DMA)', 'online softmax', 'O^T += V^T 
     col = fh[:, i + 1] - fh[:, i]
     print(f'{n:26s} {np.median(col):7.0f} {np.percentile(col, 10):6.0f} {np.percentile(col, 90):6.0f}')
 print(f'tile total                 {np.median(fh[:, 4] - fh[:, 0]):7.0f}')
+print(f'block: prologue {np.median(fh[:, 10] - fh[:, 9]):.0f}, tile loop {np.median(fh[:, 12] - fh[:, 10]):.0f} '
+      f'({s // 32} tiles), epilogue {np.median(fh[:, 13] - fh[:, 12]):.0f}, whole {np.median(fh[:, 13] - fh[:, 9]):.0f} cycles')
 nblocks = b * h
 trace = D._Buffer(8 * 16 * nblocks)
 for rep in range(3):
@@ -53,4 +55,8 @@ print('phase                      median   p10    p90   (cycles; 64 MFMAs = 4096
 for i, n in enumerate(names):
     col = dt[:, i]
     print(f'{n:26s} {np.median(col):7.0f} {np.percentile(col, 10):6.0f} {np.percentile(col, 90):6.0f}')
-print(f'tile total                 {np.median(host[:, 8] - host[:, 0]):7.0f}   (5 x 4096 = 20480 at the pipe rate)')
+print(f'tile total                 {np.median(host[:, 8] - host[:, 0]):7.0f}   (5 x 4096 = 20480 at the pipe rate; 4 x 4096 with saved scores)')
+nt = (s // 32) * (s // 128)
+print(f'block: prologue {np.median(host[:, 10] - host[:, 9]):.0f}, first key block {np.median(host[:, 11] - host[:, 10]):.0f} ({s // 32} tiles), '
+      f'all key blocks {np.median(host[:, 12] - host[:, 10]):.0f} ({nt} tiles = {np.median(host[:, 12] - host[:, 10]) / nt:.0f} per tile), '
+      f'drain {np.median(host[:, 13] - host[:, 12]):.0f}, whole {np.median(host[:, 13] - host[:, 9]):.0f} cycles')

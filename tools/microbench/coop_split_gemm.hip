@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
@@ -105,7 +106,8 @@ struct Loader {
 // ABL (timing only, results wrong): 4 no LDS stores, 1 no split/store, 2 also no global loads, 3 also no barrier
 // NB: blocks per CU (2: the LDS array is padded to 72 KB so that every variant, whatever its registers, runs two)
 // PF: how many K tiles ahead of their split the global loads are issued (1 or 2: two register sets)
-template <bool A_KMAJ, bool B_KMAJ, bool TWO_ACC, int ABL = 0, int NB = 2, int PF = 1>
+// SCHED 1: ask the scheduler to spread the split, the LDS stores and the loads between the MFMAs
+template <bool A_KMAJ, bool B_KMAJ, bool TWO_ACC, int ABL = 0, int NB = 2, int PF = 1, int SCHED = 0>
 __global__ void __launch_bounds__(256, NB)
 coop_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__restrict__ C, int M, int N, int K, long lda, long ldb, long long *clk) {
     __shared__ __attribute__((aligned(16))) char smem[(NB == 2 ? 3 : 2) * STAGE];
@@ -118,7 +120,7 @@ coop_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__res
     const int per_group = 8 * tiles_n, gid = logical / per_group, first = gid * 8;
     const int rows_in = min(8, M / TM - first), in = logical - gid * per_group;
     const int tm = first + in % rows_in, tn = in / rows_in;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int m0 = ABL == 7 ? (tm & 1) * TM : tm * TM, n0 = ABL == 7 ? 0 : tn * TN;      // ABL 7: every block reads the same few tiles (cache-hot)
     const int nkt = K / GK;
 
     Loader<A_KMAJ> la;
@@ -141,7 +143,8 @@ coop_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__res
     if (nkt > 1) { la.load(1, ga); lb.load(1, gb); }
     if (PF == 2 && nkt > 2) { la.load(2, ga2); lb.load(2, gb2); }
     __syncthreads();
-    auto iter = [&](int kt, float (&ga)[8], float (&gb)[8]) {
+    auto iter = [&](int kt, float (&ga)[8], float (&gb)[8], auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;      // the last K tile: nothing left to split or load
         const int st = (kt & 1) * STAGE;
         u32x4 a[2][3], b[2][3];
 #pragma unroll
@@ -171,7 +174,7 @@ coop_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__res
         }
         TERM(0, 0, acc[i][j])
 #undef TERM
-        if (kt + 1 < nkt) {
+        if (!LAST) {                                            // branch-free body: one scheduling region
             char *nx = smem + ((kt + 1) & 1) * STAGE;
             if (ABL < 1) {
                 la.store(nx, ga);
@@ -182,27 +185,45 @@ coop_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__res
 #pragma unroll
                 for (int t = 0; t < 4; ++t) x ^= sa.hi[t] ^ sa.mid[t] ^ sa.lo[t] ^ sb.hi[t] ^ sb.mid[t] ^ sb.lo[t];
                 if (x == 0x12345u) nx[tid] = 1;
-            } else if (ABL == 1 || ABL == 6) {
+            } else if (ABL == 1 || ABL == 6 || ABL == 7) {
                 float s = 0;
 #pragma unroll
                 for (int t = 0; t < 8; ++t) s += ga[t] + gb[t];
                 if (s == 12345.f) nx[tid] = 1;
             }
-            if ((ABL < 2 || ABL == 4) && kt + 1 + PF < nkt) { la.load(kt + 1 + PF, ga); lb.load(kt + 1 + PF, gb); }
-            if (ABL == 6 && kt + 1 + PF < nkt) {
+            if (ABL < 2 || ABL == 4 || ABL == 7) { la.load(kt + 1 + PF, ga); lb.load(kt + 1 + PF, gb); }      // past the end: in-range garbage or the descriptor's zero, never stored
+            if (ABL == 6) {
                 if (A_KMAJ) la.load_lines(kt + 1 + PF, ga, tid); else la.load(kt + 1 + PF, ga);
                 if (B_KMAJ) lb.load_lines(kt + 1 + PF, gb, tid); else lb.load(kt + 1 + PF, gb);
             }
         }
+        if (SCHED == 1 && !LAST) {
+            // 12 fragment reads first (4 before the first MFMA), then per MFMA four split instructions; the stores
+            // and loads follow the split of their operand
+            __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+#pragma unroll
+            for (int g = 0; g < 24; ++g) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                if (g < 4) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
+                if (g >= 11 && g < 14) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+                if (g >= 14 && g < 16) __builtin_amdgcn_sched_group_barrier(0x020, A_KMAJ ? 1 : 4, 0);
+                if (g >= 21 && g < 24) __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            }
+            __builtin_amdgcn_sched_group_barrier(0x020, 8, 0);
+        }
         if (ABL != 3) __syncthreads();
     };
     if (PF == 1) {
-        for (int kt = 0; kt < nkt; ++kt) iter(kt, ga, gb);
+        for (int kt = 0; kt + 1 < nkt; ++kt) iter(kt, ga, gb, std::false_type{});
+        iter(nkt - 1, ga, gb, std::true_type{});
     } else {
-        for (int kt = 0; kt < nkt; kt += 2) {       // nkt is even here
-            iter(kt, ga, gb);
-            iter(kt + 1, ga2, gb2);
+        for (int kt = 0; kt + 2 < nkt; kt += 2) {       // nkt is even here
+            iter(kt, ga, gb, std::false_type{});
+            iter(kt + 1, ga2, gb2, std::false_type{});
         }
+        iter(nkt - 2, ga, gb, std::false_type{});
+        iter(nkt - 1, ga2, gb2, std::true_type{});
     }
     if (clk && tid == 0) {
         clk[2 * blockIdx.x] = __builtin_amdgcn_s_memtime() - c0;
@@ -223,17 +244,17 @@ coop_gemm(const float *__restrict__ A, const float *__restrict__ B, float *__res
             }
 }
 
-template <bool A_KMAJ, bool B_KMAJ, bool TWO_ACC, int ABL = 0, int NB = 2, int PF = 1>
+template <bool A_KMAJ, bool B_KMAJ, bool TWO_ACC, int ABL = 0, int NB = 2, int PF = 1, int SCHED = 0>
 int run(const float *A, const float *B, float *C, int M, int N, int K, int reps, float *ms_out, long long *clk = nullptr) {
     const int grid = (M / TM) * (N / TN);
     const long lda = A_KMAJ ? K : M, ldb = B_KMAJ ? K : N;
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    coop_gemm<A_KMAJ, B_KMAJ, TWO_ACC, ABL, NB, PF><<<grid, 256>>>(A, B, C, M, N, K, lda, ldb, nullptr);
+    coop_gemm<A_KMAJ, B_KMAJ, TWO_ACC, ABL, NB, PF, SCHED><<<grid, 256>>>(A, B, C, M, N, K, lda, ldb, nullptr);
     CK(hipDeviceSynchronize());
     if (reps) {
         CK(hipEventRecord(e0));
-        for (int i = 0; i < reps; ++i) coop_gemm<A_KMAJ, B_KMAJ, TWO_ACC, ABL, NB, PF><<<grid, 256>>>(A, B, C, M, N, K, lda, ldb, clk);
+        for (int i = 0; i < reps; ++i) coop_gemm<A_KMAJ, B_KMAJ, TWO_ACC, ABL, NB, PF, SCHED><<<grid, 256>>>(A, B, C, M, N, K, lda, ldb, clk);
         CK(hipEventRecord(e1));
         CK(hipDeviceSynchronize());
         CK(hipEventElapsedTime(ms_out, e0, e1));
@@ -277,10 +298,10 @@ int check(const char *name) {
 
 long long *g_clk = nullptr;
 
-template <bool A_KMAJ, bool B_KMAJ, bool TWO, int ABL, int NB = 2, int PF = 1>
+template <bool A_KMAJ, bool B_KMAJ, bool TWO, int ABL, int NB = 2, int PF = 1, int SCHED = 0>
 int ablate_one(const char *what, int M, int N, int K, const float *A, const float *B, float *C) {
     float ms = 0;
-    if (run<A_KMAJ, B_KMAJ, TWO, ABL, NB, PF>(A, B, C, M, N, K, 5, &ms, g_clk)) return 1;
+    if (run<A_KMAJ, B_KMAJ, TWO, ABL, NB, PF, SCHED>(A, B, C, M, N, K, 5, &ms, g_clk)) return 1;
     std::vector<long long> h(2 * (size_t)(M / TM) * (N / TN));
     CK(hipMemcpy(h.data(), g_clk, h.size() * 8, hipMemcpyDeviceToHost));
     double cyc = 0, real = 0;
@@ -293,6 +314,9 @@ template <bool A_KMAJ, bool B_KMAJ>
 int ablate(const char *name, int M, int N, int K, const float *A, const float *B, float *C) {
     printf("%s M=%d N=%d K=%d, two accumulators:\n", name, M, N, K);
     return ablate_one<A_KMAJ, B_KMAJ, true, 0>("full", M, N, K, A, B, C) ||
+           ablate_one<A_KMAJ, B_KMAJ, true, 0, 2, 1, 1>("full, interleaved", M, N, K, A, B, C) ||
+           ablate_one<A_KMAJ, B_KMAJ, false, 0, 2, 1, 1>("one acc full, interleaved", M, N, K, A, B, C) ||
+           ablate_one<A_KMAJ, B_KMAJ, false, 0, 3, 1, 1>("one acc 3/CU, interleaved", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 0, 2, 2>("full, loads 2 tiles ahead", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 1, 2, 2>("no split/stores, 2 ahead", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, false, 0, 2, 2>("one acc full, 2 ahead", M, N, K, A, B, C) ||
@@ -300,6 +324,7 @@ int ablate(const char *name, int M, int N, int K, const float *A, const float *B
            ablate_one<A_KMAJ, B_KMAJ, true, 4>("no LDS stores", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 1>("no split, no stores", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 6>("same, whole-line loads", M, N, K, A, B, C) ||
+           ablate_one<A_KMAJ, B_KMAJ, true, 7>("same, cache-hot panels", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 2>("+ no global loads", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 3>("+ no barrier", M, N, K, A, B, C) ||
            ablate_one<A_KMAJ, B_KMAJ, true, 5>("no loads, 16x16x32 MFMAs", M, N, K, A, B, C) ||
