@@ -26,6 +26,9 @@ int fail(int code, const char *fmt, ...);
 int colsum_launch(const float *x, float *out, long rows, long cols, long ld);
 void set_ln_bwd_blocks(int blocks_per_cu);
 void set_ew_grid_cap(int blocks);
+void set_stream_nt(int on);
+// streaming tensors of at least 32 MB move with the nontemporal cache hint (npm_rowops.hip; NPM_TUNE_STREAM_NT)
+bool stream_nt_enabled(size_t bytes);
 // the arithmetic the most recent matrix-product launch actually ran (npm_last_math): NPM_MATH_*
 void note_math(int mode);
 

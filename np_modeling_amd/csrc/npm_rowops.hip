@@ -12,6 +12,30 @@
 namespace {
 
 int g_ln_bwd_blocks_per_cu = 4;     // NPM_TUNE_LN_BWD_BLOCKS
+int g_stream_nt = 1;                // NPM_TUNE_STREAM_NT
+
+// Streaming tensors (read once / written once, far larger than the 32 MB of L2) move with the NONTEMPORAL hint: they
+// do not displace what the GEMMs around them keep in L2 and the Infinity Cache, and from cold caches the kernels
+// themselves run faster (LayerNorm backward 131072 x 1024: 0.439 -> 0.381 ms, profiles/r02_stream_nt.log).  Small
+// tensors (parameters, partial sums) keep the default policy.
+inline bool stream_nt(size_t bytes) { return g_stream_nt && bytes >= ((size_t)32 << 20); }
+
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+template <bool NT>
+__device__ __forceinline__ float4 ldg4(const float *p) {
+    if (NT) {
+        const f32x4v v = __builtin_nontemporal_load(reinterpret_cast<const f32x4v *>(p));
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    return *reinterpret_cast<const float4 *>(p);
+}
+template <bool NT>
+__device__ __forceinline__ void stg4(float *p, const float4 &v) {
+    if (NT) __builtin_nontemporal_store(f32x4v{v.x, v.y, v.z, v.w}, reinterpret_cast<f32x4v *>(p));
+    else *reinterpret_cast<float4 *>(p) = v;
+}
+// launch KERNEL<..., NT> with NT chosen at run time
+#define NPM_NT_LAUNCH(nt, LAUNCH) do { if (nt) { constexpr bool NT = true; LAUNCH; } else { constexpr bool NT = false; LAUNCH; } } while (0)
 
 constexpr int WAVE = 64;
 constexpr int ROWS_PER_BLOCK = 4;          // 256 threads = 4 waves, one row per wave
@@ -45,7 +69,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 // operand and lane), grid-stride over the rest; the scalar tail handles n % 4.
 constexpr int EW_UNROLL = 4;
 
-template <typename F>
+template <typename F, bool NT>
 __global__ void __launch_bounds__(256) ew1_kernel(const float *a, float *out, size_t n, F f) {
     const size_t nv = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -53,22 +77,22 @@ __global__ void __launch_bounds__(256) ew1_kernel(const float *a, float *out, si
     for (; i + (EW_UNROLL - 1) * stride < nv; i += EW_UNROLL * stride) {
         float4 v[EW_UNROLL];
 #pragma unroll
-        for (int u = 0; u < EW_UNROLL; ++u) v[u] = reinterpret_cast<const float4 *>(a)[i + u * stride];
+        for (int u = 0; u < EW_UNROLL; ++u) v[u] = ldg4<NT>(a + 4 * (i + u * stride));
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
             v[u].x = f(v[u].x); v[u].y = f(v[u].y); v[u].z = f(v[u].z); v[u].w = f(v[u].w);
-            reinterpret_cast<float4 *>(out)[i + u * stride] = v[u];
+            stg4<NT>(out + 4 * (i + u * stride), v[u]);
         }
     }
     for (; i < nv; i += stride) {
-        float4 v = reinterpret_cast<const float4 *>(a)[i];
+        float4 v = ldg4<NT>(a + 4 * (i));
         v.x = f(v.x); v.y = f(v.y); v.z = f(v.z); v.w = f(v.w);
-        reinterpret_cast<float4 *>(out)[i] = v;
+        stg4<NT>(out + 4 * (i), v);
     }
     for (size_t t = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = f(a[t]);
 }
 
-template <typename F>
+template <typename F, bool NT>
 __global__ void __launch_bounds__(256) ew2_kernel(const float *a, const float *b, float *out, size_t n, F f) {
     const size_t nv = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
@@ -77,37 +101,37 @@ __global__ void __launch_bounds__(256) ew2_kernel(const float *a, const float *b
         float4 x[EW_UNROLL], y[EW_UNROLL];
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
-            x[u] = reinterpret_cast<const float4 *>(a)[i + u * stride];
-            y[u] = reinterpret_cast<const float4 *>(b)[i + u * stride];
+            x[u] = ldg4<NT>(a + 4 * (i + u * stride));
+            y[u] = ldg4<NT>(b + 4 * (i + u * stride));
         }
 #pragma unroll
         for (int u = 0; u < EW_UNROLL; ++u) {
             float4 v;
             v.x = f(x[u].x, y[u].x); v.y = f(x[u].y, y[u].y); v.z = f(x[u].z, y[u].z); v.w = f(x[u].w, y[u].w);
-            reinterpret_cast<float4 *>(out)[i + u * stride] = v;
+            stg4<NT>(out + 4 * (i + u * stride), v);
         }
     }
     for (; i < nv; i += stride) {
-        const float4 x = reinterpret_cast<const float4 *>(a)[i];
-        const float4 y = reinterpret_cast<const float4 *>(b)[i];
+        const float4 x = ldg4<NT>(a + 4 * (i));
+        const float4 y = ldg4<NT>(b + 4 * (i));
         float4 v;
         v.x = f(x.x, y.x); v.y = f(x.y, y.y); v.z = f(x.z, y.z); v.w = f(x.w, y.w);
-        reinterpret_cast<float4 *>(out)[i] = v;
+        stg4<NT>(out + 4 * (i), v);
     }
     for (size_t t = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += stride) out[t] = f(a[t], b[t]);
 }
 
-template <typename F>
+template <typename F, bool NT>
 __global__ void __launch_bounds__(256) ew3_kernel(const float *a, const float *b, const float *c, float *out, size_t n, F f) {
     const size_t nv = n / 4;
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        const float4 x = reinterpret_cast<const float4 *>(a)[i];
-        const float4 y = reinterpret_cast<const float4 *>(b)[i];
-        const float4 z = reinterpret_cast<const float4 *>(c)[i];
+        const float4 x = ldg4<NT>(a + 4 * (i));
+        const float4 y = ldg4<NT>(b + 4 * (i));
+        const float4 z = ldg4<NT>(c + 4 * (i));
         float4 v;
         v.x = f(x.x, y.x, z.x); v.y = f(x.y, y.y, z.y); v.z = f(x.z, y.z, z.z); v.w = f(x.w, y.w, z.w);
-        reinterpret_cast<float4 *>(out)[i] = v;
+        stg4<NT>(out + 4 * (i), v);
     }
     for (size_t i = nv * 4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
         out[i] = f(a[i], b[i], c[i]);
@@ -139,7 +163,7 @@ template <typename F>
 int ew1(const float *a, float *out, size_t n, F f) {
     if (n == 0) return NPM_OK;
     hipStream_t s = npm::ctx().stream;
-    if (aligned16(a) && aligned16(out)) hipLaunchKernelGGL(ew1_kernel<F>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, out, n, f);
+    if (aligned16(a) && aligned16(out)) NPM_NT_LAUNCH(stream_nt(4 * n), hipLaunchKernelGGL((ew1_kernel<F, NT>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, out, n, f));
     else hipLaunchKernelGGL(ew1_scalar<F>, dim3(grid_for(n)), dim3(256), 0, s, a, out, n, f);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
@@ -148,7 +172,7 @@ template <typename F>
 int ew2(const float *a, const float *b, float *out, size_t n, F f) {
     if (n == 0) return NPM_OK;
     hipStream_t s = npm::ctx().stream;
-    if (aligned16(a) && aligned16(b) && aligned16(out)) hipLaunchKernelGGL(ew2_kernel<F>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, out, n, f);
+    if (aligned16(a) && aligned16(b) && aligned16(out)) NPM_NT_LAUNCH(stream_nt(4 * n), hipLaunchKernelGGL((ew2_kernel<F, NT>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, out, n, f));
     else hipLaunchKernelGGL(ew2_scalar<F>, dim3(grid_for(n)), dim3(256), 0, s, a, b, out, n, f);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
@@ -158,7 +182,7 @@ int ew3(const float *a, const float *b, const float *c, float *out, size_t n, F 
     if (n == 0) return NPM_OK;
     hipStream_t s = npm::ctx().stream;
     if (aligned16(a) && aligned16(b) && aligned16(c) && aligned16(out))
-        hipLaunchKernelGGL(ew3_kernel<F>, dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, c, out, n, f);
+        NPM_NT_LAUNCH(stream_nt(4 * n), hipLaunchKernelGGL((ew3_kernel<F, NT>), dim3(grid_for(n / 4 + 1)), dim3(256), 0, s, a, b, c, out, n, f));
     else hipLaunchKernelGGL(ew3_scalar<F>, dim3(grid_for(n)), dim3(256), 0, s, a, b, c, out, n, f);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
@@ -169,7 +193,7 @@ int ew3(const float *a, const float *b, const float *c, float *out, size_t n, F 
 // 16 threads x float4 cover a 256-B row segment, 16 row lanes per block; partial sums
 // cross the row lanes through LDS.  Stage 2 sums the chunk partials (fixed order).
 // ---------------------------------------------------------------------------------
-template <bool RELU_BWD>
+template <bool RELU_BWD, bool NT>
 __global__ void __launch_bounds__(256)
 colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, long cols, long ld,
               long rows_per_chunk, long out_ld, const float *__restrict__ dy, float *__restrict__ g) {
@@ -186,12 +210,12 @@ colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, l
         const long at = r * ld + c0;
         const float *p = x + at;
         if (full) {
-            float4 v = *reinterpret_cast<const float4 *>(p);
+            float4 v = ldg4<NT>(p);
             if (RELU_BWD) {
-                const float4 d = *reinterpret_cast<const float4 *>(dy + at);
+                const float4 d = ldg4<NT>(dy + at);
                 v.x = v.x >= 0.f ? d.x : 0.f; v.y = v.y >= 0.f ? d.y : 0.f;
                 v.z = v.z >= 0.f ? d.z : 0.f; v.w = v.w >= 0.f ? d.w : 0.f;
-                *reinterpret_cast<float4 *>(g + at) = v;
+                stg4<NT>(g + at, v);
             }
             acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
         } else {
@@ -227,7 +251,7 @@ int colsum_run(const float *x, float *out, long rows, long cols, long ld, const 
     const long rpc = (rows + chunks - 1) / chunks;
     chunks = (rows + rpc - 1) / rpc;
     if (chunks <= 1) {
-        hipLaunchKernelGGL(colsum_kernel<RELU_BWD>, dim3(strips, 1), dim3(256), 0, s, x, out, rows, cols, ld,
+        hipLaunchKernelGGL((colsum_kernel<RELU_BWD, false>), dim3(strips, 1), dim3(256), 0, s, x, out, rows, cols, ld,
                            std::max<long>(rows, 1), cols, dy, g);
         NPM_CHECK_LAUNCH();
         return NPM_OK;
@@ -235,10 +259,11 @@ int colsum_run(const float *x, float *out, long rows, long cols, long ld, const 
     npm::Scratch part;
     int rc = part.alloc(sizeof(float) * (size_t)chunks * cols);
     if (rc) return rc;
-    hipLaunchKernelGGL(colsum_kernel<RELU_BWD>, dim3(strips, (int)chunks), dim3(256), 0, s, x, (float *)part.ptr, rows, cols, ld,
-                       rpc, cols, dy, g);
+    NPM_NT_LAUNCH(stream_nt(sizeof(float) * (size_t)rows * cols),
+                  hipLaunchKernelGGL((colsum_kernel<RELU_BWD, NT>), dim3(strips, (int)chunks), dim3(256), 0, s, x, (float *)part.ptr, rows, cols, ld,
+                                     rpc, cols, dy, g));
     NPM_CHECK_LAUNCH();
-    hipLaunchKernelGGL(colsum_kernel<false>, dim3(strips, 1), dim3(256), 0, s, (const float *)part.ptr, out, chunks, cols, cols,
+    hipLaunchKernelGGL((colsum_kernel<false, false>), dim3(strips, 1), dim3(256), 0, s, (const float *)part.ptr, out, chunks, cols, cols,
                        chunks, cols, (const float *)nullptr, (float *)nullptr);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
@@ -254,25 +279,25 @@ int colsum_impl(const float *x, float *out, long rows, long cols, long ld) {
 // lives in registers (n <= 256*VPL).  Rows that are not a multiple of 4 long, or longer
 // than 4096, take the generic re-reading kernels further down.
 // ---------------------------------------------------------------------------------
-template <int VPL>
+template <int VPL, bool NT>
 __device__ __forceinline__ void load_row(const float *__restrict__ p, int nvec, int lane, float4 (&v)[VPL], float fill) {
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int c = lane + WAVE * j;
-        v[j] = (c < nvec) ? reinterpret_cast<const float4 *>(p)[c] : make_float4(fill, fill, fill, fill);
+        v[j] = (c < nvec) ? ldg4<NT>(p + 4 * c) : make_float4(fill, fill, fill, fill);
     }
 }
 
-template <int VPL>
+template <int VPL, bool NT>
 __device__ __forceinline__ void store_row(float *__restrict__ p, int nvec, int lane, const float4 (&v)[VPL]) {
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
         const int c = lane + WAVE * j;
-        if (c < nvec) reinterpret_cast<float4 *>(p)[c] = v[j];
+        if (c < nvec) stg4<NT>(p + 4 * c, v[j]);
     }
 }
 
-template <int VPL>
+template <int VPL, bool NT>
 __global__ void __launch_bounds__(256)
 softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long rows, int n, float scale) {
     const int lane = threadIdx.x & 63;
@@ -280,7 +305,7 @@ softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long rows
     if (row >= rows) return;
     const int nvec = n >> 2;
     float4 v[VPL];
-    load_row<VPL>(x + row * n, nvec, lane, v, -INFINITY);
+    load_row<VPL, NT>(x + row * n, nvec, lane, v, -INFINITY);
     float m = -INFINITY;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) {
@@ -299,10 +324,10 @@ softmax_fwd_kernel(const float *__restrict__ x, float *__restrict__ y, long rows
     const float inv = 1.0f / s;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) { v[j].x *= inv; v[j].y *= inv; v[j].z *= inv; v[j].w *= inv; }
-    store_row<VPL>(y + row * n, nvec, lane, v);
+    store_row<VPL, NT>(y + row * n, nvec, lane, v);
 }
 
-template <int VPL>
+template <int VPL, bool NT>
 __global__ void __launch_bounds__(256)
 softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, float *__restrict__ dx,
                    long rows, int n, float scale) {
@@ -311,8 +336,8 @@ softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, fl
     if (row >= rows) return;
     const int nvec = n >> 2;
     float4 p[VPL], g[VPL];
-    load_row<VPL>(y + row * n, nvec, lane, p, 0.f);
-    load_row<VPL>(dy + row * n, nvec, lane, g, 0.f);
+    load_row<VPL, NT>(y + row * n, nvec, lane, p, 0.f);
+    load_row<VPL, NT>(dy + row * n, nvec, lane, g, 0.f);
     float dot = 0.f;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) dot += (p[j].x * g[j].x + p[j].y * g[j].y) + (p[j].z * g[j].z + p[j].w * g[j].w);
@@ -322,7 +347,7 @@ softmax_bwd_kernel(const float *__restrict__ y, const float *__restrict__ dy, fl
         g[j].x = scale * p[j].x * (g[j].x - dot); g[j].y = scale * p[j].y * (g[j].y - dot);
         g[j].z = scale * p[j].z * (g[j].z - dot); g[j].w = scale * p[j].w * (g[j].w - dot);
     }
-    store_row<VPL>(dx + row * n, nvec, lane, g);
+    store_row<VPL, NT>(dx + row * n, nvec, lane, g);
 }
 
 // generic (any n, any alignment): re-reads the row; served by L2 after the first pass
@@ -358,6 +383,7 @@ softmax_bwd_generic(const float *__restrict__ y, const float *__restrict__ dy, f
 
 // out[(b*H + h)*S + s] = sum_d a[b,s,h,d] * b[b,s,h,d].  Half a wavefront (32 lanes x float4) covers a
 // 128-wide head; general dims loop.  Reads both tensors once (8 B/element).
+template <bool NT>
 __global__ void __launch_bounds__(256)
 attn_rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b, float *__restrict__ out,
                    long batch, long seq, long heads, long dim) {
@@ -369,7 +395,7 @@ attn_rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b, flo
     float acc = 0.f;
     if ((dim & 3) == 0 && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0) {
         for (long c = sub * 4; c < dim; c += 128) {
-            const float4 x = *reinterpret_cast<const float4 *>(pa + c), y = *reinterpret_cast<const float4 *>(pb + c);
+            const float4 x = ldg4<NT>(pa + c), y = ldg4<NT>(pb + c);
             acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
         }
     } else {
@@ -385,7 +411,7 @@ attn_rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b, flo
 }
 
 // ---- LayerNorm ---------------------------------------------------------------------
-template <int VPL>
+template <int VPL, bool NT>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                      float eps, long rows, int d, float *__restrict__ z, float *__restrict__ mean_out,
@@ -395,7 +421,7 @@ layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamm
     if (row >= rows) return;
     const int nvec = d >> 2;
     float4 v[VPL];
-    load_row<VPL>(x + row * d, nvec, lane, v, 0.f);
+    load_row<VPL, NT>(x + row * d, nvec, lane, v, 0.f);
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -422,7 +448,7 @@ layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamm
             v[j].w = gm.w * ((v[j].w - mean) * rstd) + bt.w;
         }
     }
-    store_row<VPL>(z + row * d, nvec, lane, v);
+    store_row<VPL, NT>(z + row * d, nvec, lane, v);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
@@ -448,7 +474,7 @@ layernorm_fwd_generic(const float *__restrict__ x, const float *__restrict__ gam
 // Backward: each wave walks rows (grid-stride) and keeps its dgamma/dbeta partials for the
 // columns it owns in registers; every wave writes one partial row and a column sum over
 // the wave partials (fixed order, reproducible) finishes the job.
-template <int VPL>
+template <int VPL, bool NT>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
                      const float *__restrict__ rstd, const float *__restrict__ gamma,
@@ -470,9 +496,9 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
     // doubled the registers and changed nothing (0.334 -> 0.330 ms): this kernel is not latency-bound.
     for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
         float4 g[VPL], yh[VPL], res[VPL];
-        load_row<VPL>(dz + row * d, nvec, lane, g, 0.f);
-        load_row<VPL>(x + row * d, nvec, lane, yh, 0.f);
-        if (residual) load_row<VPL>(residual + row * d, nvec, lane, res, 0.f);
+        load_row<VPL, NT>(dz + row * d, nvec, lane, g, 0.f);
+        load_row<VPL, NT>(x + row * d, nvec, lane, yh, 0.f);
+        if (residual) load_row<VPL, NT>(residual + row * d, nvec, lane, res, 0.f);
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -496,7 +522,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
             o.z = rs * (g[j].z - m1 - yh[j].z * m2); o.w = rs * (g[j].w - m1 - yh[j].w * m2);
             if (c < nvec) {
                 if (residual) { o.x += res[j].x; o.y += res[j].y; o.z += res[j].z; o.w += res[j].w; }
-                reinterpret_cast<float4 *>(dx + row * d)[c] = o;
+                stg4<NT>(dx + row * d + 4 * c, o);
             }
         }
     }
@@ -559,6 +585,8 @@ layernorm_bwd_dx_generic(const float *__restrict__ dz, const float *__restrict__
 
 namespace npm {
 void set_ln_bwd_blocks(int v) { g_ln_bwd_blocks_per_cu = v > 0 ? v : 4; }
+void set_stream_nt(int v) { g_stream_nt = v != 0; }
+bool stream_nt_enabled(size_t bytes) { return stream_nt(bytes); }
 void set_ew_grid_cap(int v) { g_ew_grid_cap = v > 0 ? v : (1 << 20); }
 int colsum_launch(const float *x, float *out, long rows, long cols, long ld) { return colsum_impl(x, out, rows, cols, ld); }
 }  // namespace npm
@@ -624,14 +652,20 @@ int npm_relu_bwd_colsum(const float *x_pre, const float *dy, float *dx, float *c
     return colsum_run<true>(x_pre, colsum, rows, cols, cols, dy, dx);
 }
 
+#define NPM_ROW_DISPATCH_NT(KERNEL, NT, n, ...)                                                          \
+    do {                                                                                                 \
+        if (n <= 256) hipLaunchKernelGGL((KERNEL<1, NT>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);       \
+        else if (n <= 512) hipLaunchKernelGGL((KERNEL<2, NT>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);  \
+        else if (n <= 1024) hipLaunchKernelGGL((KERNEL<4, NT>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if (n <= 2048) hipLaunchKernelGGL((KERNEL<8, NT>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<16, NT>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);               \
+    } while (0)
+// one wave per row; rows x n floats stream through once: nontemporal when that is far more than the caches hold
 #define NPM_ROW_DISPATCH(KERNEL, n, ...)                                                       \
     do {                                                                                       \
         const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);                  \
-        if (n <= 256) hipLaunchKernelGGL(KERNEL<1>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
-        else if (n <= 512) hipLaunchKernelGGL(KERNEL<2>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
-        else if (n <= 1024) hipLaunchKernelGGL(KERNEL<4>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
-        else if (n <= 2048) hipLaunchKernelGGL(KERNEL<8>, dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
-        else hipLaunchKernelGGL(KERNEL<16>, dim3(grid), dim3(256), 0, s, __VA_ARGS__);         \
+        if (stream_nt(sizeof(float) * (size_t)rows * (size_t)(n))) NPM_ROW_DISPATCH_NT(KERNEL, true, n, __VA_ARGS__); \
+        else NPM_ROW_DISPATCH_NT(KERNEL, false, n, __VA_ARGS__);                               \
     } while (0)
 
 int npm_attn_rowdot(const float *a, const float *b, float *out, int64_t batch, int64_t seq, int64_t heads, int64_t dim) {
@@ -642,8 +676,9 @@ int npm_attn_rowdot(const float *a, const float *b, float *out, int64_t batch, i
     NPM_ARG(a && b && out);
     const long blocks = (rows * 32 + 255) / 256;
     NPM_ARG(blocks < (1L << 31));
-    hipLaunchKernelGGL(attn_rowdot_kernel, dim3((int)blocks), dim3(256), 0, npm::ctx().stream, a, b, out,
-                       (long)batch, (long)seq, (long)heads, (long)dim);
+    NPM_NT_LAUNCH(stream_nt(sizeof(float) * (size_t)rows * (size_t)dim),
+                  hipLaunchKernelGGL(attn_rowdot_kernel<NT>, dim3((int)blocks), dim3(256), 0, npm::ctx().stream, a, b, out,
+                                     (long)batch, (long)seq, (long)heads, (long)dim));
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }
@@ -724,13 +759,10 @@ int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const 
         int rc = part.alloc(sizeof(float) * 2 * (size_t)grid * d);
         if (rc) return rc;
         float *pp = (float *)part.ptr;                     // [grid][2 d]: dgamma partials | dbeta partials
-#define NPM_LNB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp)
-        if (d <= 256) NPM_LNB(1);
-        else if (d <= 512) NPM_LNB(2);
-        else if (d <= 1024) NPM_LNB(4);
-        else if (d <= 2048) NPM_LNB(8);
-        else NPM_LNB(16);
-#undef NPM_LNB
+        if (stream_nt(sizeof(float) * (size_t)rows * (size_t)d))
+            NPM_ROW_DISPATCH_NT(layernorm_bwd_kernel, true, d, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
+        else
+            NPM_ROW_DISPATCH_NT(layernorm_bwd_kernel, false, d, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
         NPM_CHECK_LAUNCH();
         if (dbeta == dgamma + d) return colsum_impl(pp, dgamma, grid, 2 * d, 2 * d);      // adjacent outputs (the gradient bucket): one pass
         rc = colsum_impl(pp, dgamma, grid, d, 2 * d);
