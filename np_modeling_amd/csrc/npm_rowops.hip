@@ -13,6 +13,7 @@ namespace {
 
 int g_ln_bwd_blocks_per_cu = 4;     // NPM_TUNE_LN_BWD_BLOCKS
 int g_stream_nt = 1;                // NPM_TUNE_STREAM_NT
+int g_colsum_blocks_per_cu = 8;     // whole-line column sums: grid = this x CUs (experiment knob: NPM_TUNE_EW_GRID_CAP < 0 sets it)
 
 // Streaming tensors (read once / written once, far larger than the 32 MB of L2) move with the NONTEMPORAL hint: they
 // do not displace what the GEMMs around them keep in L2 and the Infinity Cache, and from cold caches the kernels
@@ -206,7 +207,29 @@ colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, l
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
     bool full = (c0 + 3 < cols) && (ld % 4 == 0) && ((((uintptr_t)x) & 15) == 0);
     if (RELU_BWD) full = full && ((((uintptr_t)dy) & 15) == 0) && ((((uintptr_t)g) & 15) == 0);
-    for (long r = r_beg + rl; r < r_end; r += 16) {
+    long r = r_beg + rl;
+    if (full) {
+        // four rows per thread and iteration, every load issued before the first use (128 B in flight per lane)
+        for (; r + 48 < r_end; r += 64) {
+            float4 v[4], d[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const long at = (r + 16 * u) * ld + c0;
+                v[u] = ldg4<NT>(x + at);
+                if (RELU_BWD) d[u] = ldg4<NT>(dy + at);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (RELU_BWD) {
+                    v[u].x = v[u].x >= 0.f ? d[u].x : 0.f; v[u].y = v[u].y >= 0.f ? d[u].y : 0.f;
+                    v[u].z = v[u].z >= 0.f ? d[u].z : 0.f; v[u].w = v[u].w >= 0.f ? d[u].w : 0.f;
+                    stg4<NT>(g + (r + 16 * u) * ld + c0, v[u]);
+                }
+                acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+            }
+        }
+    }
+    for (; r < r_end; r += 16) {
         const long at = r * ld + c0;
         const float *p = x + at;
         if (full) {
@@ -242,10 +265,90 @@ colsum_kernel(const float *__restrict__ x, float *__restrict__ out, long rows, l
     }
 }
 
+// Narrow dense matrices (cols divides 1024, e.g. the 128 output channels of C3's Conv2D: 12.8 M rows): 1024 / cols
+// consecutive rows are one 4 KB line of 1024 floats; a block streams whole lines (256 threads x 16 bytes, four lines
+// per iteration, every load issued before the first use) and thread t keeps the sums of its four columns in registers:
+// no LDS, no strided 256-byte strips.  part[block][1024] then folds to [cols] in the ordinary second stage
+// (its rows are (block, line position) pairs).
+template <bool RELU_BWD, bool NT>
+__global__ void __launch_bounds__(256)
+colsum_lines_kernel(const float *__restrict__ x, float *__restrict__ part, long lines, long lines_per_block,
+                    const float *__restrict__ dy, float *__restrict__ g) {
+    // Block b owns lines [b lpb, (b + 1) lpb) (blocks striding through the tensor together measured slower: 3.9 vs
+    // 3.5-3.8 ms at C3).  Software pipeline: the next four lines are requested before the current four are reduced and
+    // stored, so loads and stores of a wave overlap instead of alternating.
+    const long l_beg = (long)blockIdx.x * lines_per_block, l_end = min(lines, l_beg + lines_per_block);
+    const int c = threadIdx.x * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fetch = [&](long l, float4 (&v)[4], float4 (&d)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            v[u] = ldg4<NT>(x + (l + u) * 1024 + c);
+            if (RELU_BWD) d[u] = ldg4<NT>(dy + (l + u) * 1024 + c);
+        }
+    };
+    auto consume = [&](long l, float4 (&v)[4], float4 (&d)[4]) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (RELU_BWD) {
+                v[u].x = v[u].x >= 0.f ? d[u].x : 0.f; v[u].y = v[u].y >= 0.f ? d[u].y : 0.f;
+                v[u].z = v[u].z >= 0.f ? d[u].z : 0.f; v[u].w = v[u].w >= 0.f ? d[u].w : 0.f;
+                stg4<NT>(g + (l + u) * 1024 + c, v[u]);
+            }
+            acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w;
+        }
+    };
+    long l = l_beg;
+    if (l + 3 < l_end) {
+        float4 v0[4], d0[4], v1[4], d1[4];
+        fetch(l, v0, d0);
+        for (; l + 11 < l_end; l += 8) {            // two groups per trip: the buffers keep their names
+            fetch(l + 4, v1, d1);
+            consume(l, v0, d0);
+            fetch(l + 8, v0, d0);
+            consume(l + 4, v1, d1);
+        }
+        if (l + 7 < l_end) {
+            fetch(l + 4, v1, d1);
+            consume(l, v0, d0);
+            consume(l + 4, v1, d1);
+            l += 8;
+        } else {
+            consume(l, v0, d0);
+            l += 4;
+        }
+    }
+    for (; l < l_end; ++l) {
+        float4 v = ldg4<NT>(x + l * 1024 + c);
+        if (RELU_BWD) {
+            const float4 d = ldg4<NT>(dy + l * 1024 + c);
+            v.x = v.x >= 0.f ? d.x : 0.f; v.y = v.y >= 0.f ? d.y : 0.f;
+            v.z = v.z >= 0.f ? d.z : 0.f; v.w = v.w >= 0.f ? d.w : 0.f;
+            stg4<NT>(g + l * 1024 + c, v);
+        }
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4 *>(part + (long)blockIdx.x * 1024 + c) = acc;
+}
+
 template <bool RELU_BWD>
 int colsum_run(const float *x, float *out, long rows, long cols, long ld, const float *dy, float *g) {
     hipStream_t s = npm::ctx().stream;
     if (rows <= 0) return ew1(out, out, (size_t)cols, FillF{0.f});          // an empty batch sums to zero
+    if (ld == cols && cols >= 4 && cols < 1024 && 1024 % cols == 0 && rows % (1024 / cols) == 0 && rows * cols >= (1L << 22) &&
+        aligned16(x) && (!RELU_BWD || (aligned16(dy) && aligned16(g)))) {
+        const long lines = rows / (1024 / cols);
+        const long blocks = std::min<long>(lines / 16, (long)g_colsum_blocks_per_cu * npm::ctx().num_cus);   // >= 16 lines per block
+        const long lpb = (lines + blocks - 1) / blocks;
+        const long used = (lines + lpb - 1) / lpb;
+        npm::Scratch part;
+        int rc = part.alloc(sizeof(float) * (size_t)used * 1024);
+        if (rc) return rc;
+        NPM_NT_LAUNCH(stream_nt(sizeof(float) * (size_t)rows * cols),
+                      hipLaunchKernelGGL((colsum_lines_kernel<RELU_BWD, NT>), dim3((int)used), dim3(256), 0, s, x, (float *)part.ptr, lines, lpb, dy, g));
+        NPM_CHECK_LAUNCH();
+        return colsum_run<false>((const float *)part.ptr, out, used * (1024 / cols), cols, cols, nullptr, nullptr);
+    }
     const int strips = (int)((cols + 63) / 64);
     long chunks = std::max<long>(1, std::min<long>((rows + 255) / 256, std::max<long>(1, 2048 / strips)));
     const long rpc = (rows + chunks - 1) / chunks;
@@ -587,7 +690,7 @@ namespace npm {
 void set_ln_bwd_blocks(int v) { g_ln_bwd_blocks_per_cu = v > 0 ? v : 4; }
 void set_stream_nt(int v) { g_stream_nt = v != 0; }
 bool stream_nt_enabled(size_t bytes) { return stream_nt(bytes); }
-void set_ew_grid_cap(int v) { g_ew_grid_cap = v > 0 ? v : (1 << 20); }
+void set_ew_grid_cap(int v) { if (v < 0) g_colsum_blocks_per_cu = -v; else g_ew_grid_cap = v > 0 ? v : (1 << 20); }
 int colsum_launch(const float *x, float *out, long rows, long cols, long ld) { return colsum_impl(x, out, rows, cols, ld); }
 }  // namespace npm
 

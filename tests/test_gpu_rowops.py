@@ -52,7 +52,8 @@ def test_elementwise_unaligned_views(env):
     np.testing.assert_array_equal(out.numpy(), 2 * np.arange(1, 998, dtype=np.float32))
 
 
-@pytest.mark.parametrize('rows,cols', [(0, 6), (1, 1), (7, 5), (1000, 64), (4099, 130), (20000, 1024), (3, 4096)])
+@pytest.mark.parametrize('rows,cols', [(0, 6), (1, 1), (7, 5), (1000, 64), (4099, 130), (20000, 1024), (3, 4096),
+                                       (40008, 128), (40009, 128), (1 << 20, 4), (70000, 64)])   # >= 4 M elements, cols | 1024: whole-line kernel
 def test_colsum(env, rows, cols):
     _C, D = env
     x = np.random.default_rng(rows + cols).standard_normal((rows, cols)).astype(np.float32)
@@ -60,7 +61,8 @@ def test_colsum(env, rows, cols):
     assert_close(out, x.astype(np.float64).sum(axis=0), tol=2e-6)
 
 
-@pytest.mark.parametrize('rows,cols', [(0, 8), (1, 1), (7, 5), (1000, 64), (4099, 130), (50000, 128), (3, 4096)])
+@pytest.mark.parametrize('rows,cols', [(0, 8), (1, 1), (7, 5), (1000, 64), (4099, 130), (50000, 128), (3, 4096),
+                                       (40001, 128), (70000, 64), (66000, 256)])               # incl. odd line counts and the strip fallback
 def test_relu_bwd_colsum(env, rows, cols):
     """ReLU backward + bias gradient in one pass (activations.py:19 then conv.py:55 / mlp.py:34)."""
     _C, D = env

@@ -22,9 +22,23 @@ PEAK = 157.3
 KERNELS = False
 
 
+MIN_SECONDS = 0.5
+
+
 def timed(fn, steps, D):
+    """Seconds per step.  The card needs tens of milliseconds of continuous load to settle at its working clock: a
+    3-step region of C2 (10 ms) read 125 TF where 200 steps read 143 (profiles/r02_config_bench.log), so warm up for
+    MIN_SECONDS / 2 and time at least MIN_SECONDS."""
     fn()
     D.synchronize()
+    t0 = time.perf_counter()
+    fn()
+    D.synchronize()
+    one = max(time.perf_counter() - t0, 1e-4)
+    for _ in range(int(MIN_SECONDS / 2 / one) + 1):
+        fn()
+    D.synchronize()
+    steps = max(steps, int(MIN_SECONDS / one) + 1)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
@@ -43,13 +57,15 @@ def timed(fn, steps, D):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--steps', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=3, help='at least this many timed steps (and at least --min-seconds of them)')
+    ap.add_argument('--min-seconds', type=float, default=0.5)
     ap.add_argument('--only', default='')
     ap.add_argument('--conv-batch', type=int, default=256)
     ap.add_argument('--kernels', action='store_true', help='per-kernel HIP-event table after each line')
     args = ap.parse_args()
-    global KERNELS
+    global KERNELS, MIN_SECONDS
     KERNELS = args.kernels
+    MIN_SECONDS = args.min_seconds
     import np_modeling_amd as npm
     from np_modeling_amd import device as D
     rng = np.random.default_rng(0)

@@ -9,8 +9,11 @@ from np_modeling_amd import device as D, _C
 
 # usage: gemm_trace.py [K]            -> 131072 x 1024 x K, NN
 #        gemm_trace.py qk             -> the attention score GEMM: 2048 x (512 x 512 x 128), NT
+#        gemm_trace.py c2             -> 4096^3, NN
 if len(sys.argv) > 1 and sys.argv[1] == 'qk':
     M, N, K, NB, NT = 512, 512, 128, 2048, True
+elif len(sys.argv) > 1 and sys.argv[1] == 'c2':          # C2's forward: 1024 tiles = one generation of 4 blocks per CU
+    M, N, K, NB, NT = 4096, 4096, 4096, 1, False
 else:
     M, N, K, NB, NT = 131072, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 1, False
 rng = np.random.default_rng(0)
@@ -63,3 +66,15 @@ for k, ids in groups.items():
     gaps.extend(np.diff(s))
 gaps = np.array(gaps)
 print('gap between consecutive block starts on a CU: p10 %d p50 %d p90 %d' % tuple(np.percentile(gaps, [10, 50, 90])))
+
+# one-generation launches: who finishes when (a static partition lasts as long as its slowest CU)
+per_xcc = collections.defaultdict(list)
+for i in range(grid):
+    per_xcc[int(xcc[i])].append(i)
+print('per XCC: blocks, median main-loop ticks, median end, max end (us)')
+for x in sorted(per_xcc):
+    ids = per_xcc[x]
+    print(f'  xcc {x}: {len(ids):5d}  loop {np.median((loop - first)[ids]) * us:8.1f}  end median {np.median(end[ids]) * us:8.1f}  max {end[ids].max() * us:8.1f}  start max {start[ids].max() * us:6.1f}')
+e = np.sort(end) * us
+print('block end times (us): p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f' % tuple(np.percentile(e, [1, 10, 50, 90, 99, 100])))
+print('main loop per k-tile (ns): p10 %.1f p50 %.1f p90 %.1f' % tuple(np.percentile((loop - first) / (K // 16) * us * 1000, [10, 50, 90])))
