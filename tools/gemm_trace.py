@@ -14,11 +14,18 @@ if len(sys.argv) > 1 and sys.argv[1] == 'qk':
     M, N, K, NB, NT = 512, 512, 128, 2048, True
 elif len(sys.argv) > 1 and sys.argv[1] == 'c2':          # C2's forward: 1024 tiles = one generation of 4 blocks per CU
     M, N, K, NB, NT = 4096, 4096, 4096, 1, False
+elif len(sys.argv) > 3:                                  # gemm_trace.py M N K
+    M, N, K, NB, NT = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), 1, False
 else:
     M, N, K, NB, NT = 131072, 1024, int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 1, False
 rng = np.random.default_rng(0)
-a = D.from_host(rng.standard_normal(NB * M * K, dtype=np.float32))
-b = D.from_host(rng.standard_normal(NB * K * N, dtype=np.float32))
+def filled(n):
+    out, chunk = D.empty([n]), rng.standard_normal(min(n, 1 << 22), dtype=np.float32)
+    for o in range(0, n, chunk.size):
+        m = min(chunk.size, n - o)
+        out.flat_view(o, [m]).set(chunk[:m])
+    return out
+a, b = filled(NB * M * K), filled(NB * K * N)
 c = D.empty([NB * M * N])
 grid = NB * (M // 128) * (N // 128)
 buf = D._Buffer(grid * 64)
@@ -26,9 +33,11 @@ if NT:
     fn = lambda: D.gemm(M, N, K, D.Mat(a, K, M * K), D.Mat(b, K, N * K), D.Mat(c, N, M * N), trans_b=True, batch=(NB, 1))
 else:
     fn = lambda: D.gemm(M, N, K, D.Mat(a, K), D.Mat(b, N), D.Mat(c, N))
-fn(); fn(); D.synchronize()
+for _ in range(12): fn()
+D.synchronize()
 _C.check(_C.lib().npm_debug_gemm_trace(buf.ptr))
-fn(); D.synchronize()
+ev0 = D.Event().record(); fn(); ev1 = D.Event().record(); D.synchronize()
+kernel_ms = ev0.elapsed_ms(ev1)
 _C.check(_C.lib().npm_debug_gemm_trace(None))
 host = np.empty(grid * 8, dtype=np.int64)
 _C.check(_C.lib().npm_d2h(host.ctypes.data, buf.ptr, host.nbytes))
@@ -78,3 +87,11 @@ for x in sorted(per_xcc):
 e = np.sort(end) * us
 print('block end times (us): p1 %.1f p10 %.1f p50 %.1f p90 %.1f p99 %.1f max %.1f' % tuple(np.percentile(e, [1, 10, 50, 90, 99, 100])))
 print('main loop per k-tile (ns): p10 %.1f p50 %.1f p90 %.1f' % tuple(np.percentile((loop - first) / (K // 16) * us * 1000, [10, 50, 90])))
+
+busy_us = float(real.sum()) / 100.0            # block lifetimes on the 100 MHz wall clock
+clock_ghz = 1e-3 / us                       # s_memtime ticks are shader cycles
+mfma_cycles = grid * (K // 16) * 32 * 64 * 4 / (len(groups) * 4)          # per SIMD: 32 f32 MFMAs of 64 cycles per wave and k-tile
+print(f'matrix pipe: {mfma_cycles / (kernel_ms * 1e3 * clock_ghz * 1e3) * 100:.1f} % of the cycles of the launch at {clock_ghz:.2f} GHz '
+      f'(nominal 2.4): cycles x clock = {mfma_cycles / (kernel_ms * 1e3 * clock_ghz * 1e3) * clock_ghz / 2.4 * 100:.1f} % of 157.3 TF')
+print(f'traced launch {kernel_ms * 1e3:.1f} us = {2.0 * NB * M * N * K / kernel_ms * 1e-9:.1f} TF; sum of block lifetimes {busy_us:.0f} us '
+      f'= {busy_us / (kernel_ms * 1e3) / len(groups):.2f} resident blocks per CU on average (4 fit)')

@@ -17,7 +17,9 @@ echo "== config bench"; { for m in f32 bf16x3 bf16x3_fast; do echo "NPM_MATH=$m"
 echo "== gemm shapes"; { for t in 10=0 10=2 10=1; do timeout -k 10 200 python tools/gemm_bench.py --tune $t; done; } > "$OUT/${R}_gemm_shapes.log" 2>&1
 echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/${R}_rowops.log" 2>&1
 echo "== math error"; timeout -k 10 100 python tools/math_bias.py > "$OUT/${R}_math_error.log" 2>&1
-echo "== fused attention core"; { timeout -k 10 100 python tools/attn_bench.py; timeout -k 10 100 python tools/attn_bench.py --save-scores; NPM_ATTN_CORE=1 timeout -k 10 100 python tools/attn_trace.py; } > "$OUT/${R}_attn_core.log" 2>&1
+echo "== fused attention core"; { timeout -k 10 100 python tools/attn_bench.py; timeout -k 10 100 python tools/attn_bench.py --save-scores; echo "-- stamps, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved (the default)"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
+echo "== GEMM block timelines"; { for sh in "131072 1024 1024" "131072 4096 1024" "131072 1024 4096" "3211264 128 576" c2; do timeout -k 10 100 python tools/gemm_trace.py $sh 2>&1 | grep -E "^K=|^in us|^traced|^matrix pipe"; done; } > "$OUT/${R}_gemm_timeline.log" 2>&1
+echo "== split-bf16 prototype and ablations"; ( cd tools/microbench && { [ -x coop_split_gemm ] || hipcc -O3 --offload-arch=gfx950 coop_split_gemm.hip -o coop_split_gemm; } && timeout -k 10 200 ./coop_split_gemm ) > "$OUT/${R}_coop_split_gemm.log" 2>&1
 echo "== f32 MFMA issue microbenchmark"; timeout -k 10 60 tools/microbench/mfma_f32_chain > "$OUT/${R}_mfma_f32_chain.log" 2>&1
 echo "== parity report"; timeout -k 10 600 python tools/parity_report.py > "$OUT/${R}_parity_relative_error.log" 2>&1
 echo "== attention: fused core against the GEMM composition, whole step"; { for cfg in "NPM_ATTN_CORE=0" "NPM_ATTN_CORE=1 NPM_ATTN_SAVE_SCORES=0" "NPM_ATTN_CORE=1 NPM_ATTN_SAVE_SCORES=1"; do echo "$cfg: $(env $cfg timeout -k 10 200 python bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-alt-math 2>/dev/null | python3 -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value'],1),'samples/s',round(d['ms_per_step'],2),'ms/step')")"; done; } > "$OUT/${R}_attn_step_ab.log" 2>&1
