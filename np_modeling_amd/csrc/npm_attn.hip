@@ -235,7 +235,7 @@ mha_fwd_kernel(const MhaArgs p) {
     }
     if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nt; ++t) {
-        __syncthreads();                                // tile t has landed; nobody still reads the stage refilled next
+        npm_tile::dma_barrier();                        // tile t has landed (every wave's pieces); nobody still reads the stage refilled next
         long long *tr = (p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
         if (p.trace && tid == 0 && t == (nt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime(); FENCE(); }
         STAMP(0);

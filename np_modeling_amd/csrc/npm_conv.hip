@@ -290,7 +290,7 @@ conv_fwd_glds_kernel(const ConvArgs p) {
     if (nkt > 0) NPM_CONV_ISSUE(0, 0);
     prio_low(p.e.prio & 1);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
+        dma_barrier();
         if (kt + 1 < nkt) NPM_CONV_ISSUE(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * STAGE;
         mma_tile16_math<MATH, true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
@@ -382,7 +382,7 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
     if (nkt > 0) issue(0, 0);
     prio_low(p.e.prio & 1);
     for (int kt = 0; kt < nkt; ++kt) {
-        __syncthreads();
+        dma_barrier();
         if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
         const float *sA = smem + (kt & 1) * G_STAGE;
         if (wave_has_rows) mma_tile16_math<MATH, false, false>(sA, sA + G_TILE, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));

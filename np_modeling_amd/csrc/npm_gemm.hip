@@ -260,7 +260,7 @@ sgemm_glds_kernel(const GemmArgs p) {
             asm volatile("" ::: "memory");
             if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
         } else {
-            if (!(p.ablate & 4)) __syncthreads();
+            if (!(p.ablate & 4)) dma_barrier();
             if (p.trace && kt == 0) t_first = __builtin_amdgcn_s_memtime();
             if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
         }

@@ -409,6 +409,16 @@ __device__ __forceinline__ void lds_dma16(__amdgpu_buffer_rsrc_t rsrc, float *ld
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, (lds_void *)lds, 16, voffset, soffset, 0, 0);
 }
 
+// The barrier of an LDS-DMA pipeline: every piece THIS wave issued has landed (vmcnt), then the workgroup barrier, so
+// every wave's pieces have.  The wait is explicit on purpose: hipcc's wait-count insertion does not treat a pending
+// buffer_load ... lds as something a later ds_read of those bytes depends on, and emits `s_waitcnt lgkmcnt(0)` only in
+// front of a __syncthreads() unless an ordinary load happens to be outstanding too (found with the HALF blocks of the
+// Conv2D filter gradient under the split-bf16 modes: short MFMA phases, stale tiles, 1e-2 errors).
+__device__ __forceinline__ void dma_barrier() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+}
+
 // WIDTH: rows (K-major) / floats per k row (MN-major) of the operand tile: 128, or 256 for the wide tile.
 template <bool KMAJ, int WIDTH = BM>
 __device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {
