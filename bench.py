@@ -120,9 +120,10 @@ def cpu_baseline(args, params):
     return out
 
 
-def alt_roofline(timer):
-    """Kernel-level roofline of the split-bf16 GEMM family against the bf16 MFMA peak: every fp32 product is executed as
-    six v_mfma_f32_32x32x16_bf16, so the pipe executes 6x the algorithmic fp32 FLOPs."""
+def alt_roofline(timer, per_product=6, kernel=None):
+    """Kernel-level roofline of a split-precision GEMM family against the 16-bit MFMA peak: every fp32 product is
+    executed as `per_product` v_mfma_f32_32x32x16 (bf16 split: 6, scaled fp16 split: 3), so the pipe executes that
+    many times the algorithmic fp32 FLOPs."""
     if timer is None:
         return None
     gemm = {k: v for k, v in timer.summary().items() if k.startswith(MFMA_BOUND)}
@@ -130,9 +131,9 @@ def alt_roofline(timer):
     launches = sum(v['launches'] for v in gemm.values())
     if ms <= 0:
         return None
-    executed = 6 * flops / (ms * 1e-3) / 1e12
-    return {'kernel': 'sgemm_glds_kernel<..., MATH = 2> (six v_mfma_f32_32x32x16_bf16 per fp32 product; attention composed from these GEMMs)',
-            'bound': 'mfma', 'achieved': executed, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (bf16 MFMA work executed)',
+    executed = per_product * flops / (ms * 1e-3) / 1e12
+    return {'kernel': kernel or 'sgemm_glds_kernel<..., MATH = 2> (six v_mfma_f32_32x32x16_bf16 per fp32 product; attention composed from these GEMMs)',
+            'bound': 'mfma', 'achieved': executed, 'peak': BF16_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s (16-bit MFMA work executed)',
             'frac': executed / BF16_MFMA_PEAK_TFLOPS, 'fp32_equivalent_tflops': flops / (ms * 1e-3) / 1e12,
             'launches': launches, 'avg_launch_ms': ms / max(launches, 1), 'traffic': None}
 
@@ -165,7 +166,7 @@ def main():
     ap.add_argument('--cpu-verbatim-seq', type=int, default=256, help='tokens of the reference-verbatim CPU sample (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timer', action='store_true')
-    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16x3_fast'],
+    ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16x3_fast', 'f16x2'],
                     help="arithmetic of the matrix products for the headline measurement (include/npm_hip.h npm_set_math)")
     ap.add_argument('--no-alt-math', action='store_true',
                     help="skip the second timed region that repeats the K steps with --math bf16x3 ('alt_math' in the JSON)")
@@ -285,10 +286,9 @@ def main():
                                 'GBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in sorted(summary.items()) if not k.startswith(MFMA_BOUND) and v['ms'] > 0},
         }
-    if args.math == 'f32' and not args.no_alt_math:
-        # Second timed region, same K steps, same barriers: the matrix products on the bf16 pipe (three-way operand
-        # split, fp32-class error -- DESIGN.md 4.1, tests/test_gpu_gemm.py::test_split_math_error_statistics).
-        npm.set_math('bf16x3')
+    def alt_region(mode):
+        """A further timed region, same K steps, same barriers, under another arithmetic of the matrix products."""
+        npm.set_math(mode)
         step()
         D.synchronize()
         if comm.active:
@@ -309,16 +309,33 @@ def main():
             alt = comm.allreduce_scalar(alt, parallel.MAX)
         npm.set_math('f32')
         alt_value = total_samples / alt
-        result['alt_math'] = {
-            'math': 'bf16x3', 'value': alt_value, 'unit': 'samples/s', 'ms_per_step': 1e3 * alt / args.steps,
-            'steps': args.steps, 'step_tflops_per_gpu': alt_value / world * fps / 1e12,
-            'step_frac_of_fp32_mfma_peak': alt_value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            'executed_bf16_mfma_frac_of_bf16_peak': 6 * alt_value / world * fps / 1e12 / BF16_MFMA_PEAK_TFLOPS,
+        return alt_timer, {'math': mode, 'value': alt_value, 'unit': 'samples/s', 'ms_per_step': 1e3 * alt / args.steps,
+                           'steps': args.steps, 'step_tflops_per_gpu': alt_value / world * fps / 1e12,
+                           'step_frac_of_fp32_mfma_peak': alt_value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+
+    if args.math == 'f32' and not args.no_alt_math:
+        # the matrix products on the bf16 pipe (three-way operand split, fp32-class error -- DESIGN.md 4.1,
+        # tests/test_gpu_gemm.py::test_split_math_error_statistics)
+        alt_timer, obj = alt_region('bf16x3')
+        obj.update({
+            'executed_bf16_mfma_frac_of_bf16_peak': 6 * obj['value'] / world * fps / 1e12 / BF16_MFMA_PEAK_TFLOPS,
             'roofline': alt_roofline(alt_timer),
             'note': 'same workload and timing protocol with npm_set_math(NPM_MATH_BF16X3): fp32 inputs/outputs/accumulators, '
                     'each product formed from three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16); '
                     'rms error vs fp64 at or below the exact-f32 MFMA path (profiles/r01_math_error.log). '
-                    'Not the headline: value above is the exact-f32 MFMA path.'}
+                    'Not the headline: value above is the exact-f32 MFMA path.'})
+        result['alt_math'] = obj
+        # ... and on the f16 pipe: two-way fp16 split with row scaling, three MFMAs per product (csrc/npm_gemm_f16x2.hip)
+        alt_timer, obj = alt_region('f16x2')
+        obj.update({
+            'roofline': alt_roofline(alt_timer, per_product=3, kernel='sgemm_f16x2_kernel (three v_mfma_f32_32x32x16_f16 per fp32 '
+                                     'product, operand maxima passes included in the launch time; attention composed from the '
+                                     'batched bf16-split GEMMs, six MFMAs per product there)'),
+            'note': 'same workload and timing protocol with npm_set_math(NPM_MATH_F16X2): every row of op(A) / column of op(B) '
+                    'scaled by a power of two, split into two fp16 parts, (hi hi + hi lo + lo hi) / (s_a s_b); error against '
+                    'fp64 below a k-ordered fp32 fma chain ROW-NORMWISE (profiles/r02_f16x2_gemm.log), not elementwise. '
+                    'Not the headline: value above is the exact-f32 MFMA path.'})
+        result['alt_math_f16x2'] = obj
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args, params)
     if rank == 0:

@@ -142,8 +142,18 @@ int npm_set_tuning(int knob, int value);
  *                         NaN where the f32 mode gives inf; operands below 2^-110 lose their low parts to underflow.
  *   NPM_MATH_BF16X3_FAST  the same six terms into one accumulator: fewer registers, faster; the matrix pipe cuts
  *                         small addends against a large accumulator, which leaves a bias of about -0.5 ulp per
- *                         4096 accumulated terms (visible in column checksums, not per element). */
-enum { NPM_MATH_F32 = 0, NPM_MATH_BF16X3_FAST = 1, NPM_MATH_BF16X3 = 2 };
+ *                         4096 accumulated terms (visible in column checksums, not per element).
+ *   NPM_MATH_F16X2        two-way fp16 split with ROW SCALING on v_mfma_f32_32x32x16_f16, three MFMAs per product: every
+ *                         row of op(A) and column of op(B) is scaled by a power of two that brings its largest magnitude
+ *                         along K to [2^13, 2^14), split into hi + lo (11 + 11 bits), and the product is
+ *                         (hi hi + hi lo + lo hi) / (s_a s_b).  The error is fp32-class ROW-NORMWISE (rms 1.4e-7 of the
+ *                         output row's largest element at K = 4096, below a k-ordered fp32 fma chain's 3.8e-7) rather
+ *                         than elementwise: an operand element more than 2^17 below its row's maximum keeps fewer than
+ *                         22 bits (absolute loss <= 2^-39 of that maximum).  inf / nan anywhere in a row or column
+ *                         make the whole output row / column nan.  Runs for single (un-batched) products on 16-byte
+ *                         aligned operands with K % 16 == 0; every other launch (batched attention products,
+ *                         convolutions, epilogue column sums) takes the bf16 split: npm_last_math() tells which ran. */
+enum { NPM_MATH_F32 = 0, NPM_MATH_BF16X3_FAST = 1, NPM_MATH_BF16X3 = 2, NPM_MATH_F16X2 = 3 };
 int npm_set_math(int mode);
 int npm_get_math(void);                  /* the mode REQUESTED with npm_set_math */
 /* The mode the most recent npm_sgemm / npm_conv2d_* / npm_mha_core_* launch actually RAN.  The split-bf16 modes exist

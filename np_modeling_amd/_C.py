@@ -236,7 +236,7 @@ def lib():
     return _LIB
 
 
-MATH_MODES = {'f32': 0, 'bf16x3_fast': 1, 'bf16x3': 2}      # include/npm_hip.h NPM_MATH_*
+MATH_MODES = {'f32': 0, 'bf16x3_fast': 1, 'bf16x3': 2, 'f16x2': 3}      # include/npm_hip.h NPM_MATH_*
 
 
 _MATH = 'f32'
@@ -249,7 +249,9 @@ def current_math() -> str:
 
 def set_math(mode: str) -> None:
     """Arithmetic of the matrix products: 'f32' (exact-fp32 MFMA, default), 'bf16x3' (three-way bf16 operand split
-    on the bf16 matrix pipe, fp32-class error) or 'bf16x3_fast' (same, one accumulator); include/npm_hip.h."""
+    on the bf16 matrix pipe, fp32-class error), 'bf16x3_fast' (same, one accumulator) or 'f16x2' (two-way fp16 split with
+    row scaling on the f16 matrix pipe: fp32-class error row-normwise; the bf16 split where it does not apply);
+    include/npm_hip.h."""
     if mode not in MATH_MODES:
         raise ValueError(f'unknown math mode {mode!r}: expected one of {sorted(MATH_MODES)}')
     global _MATH

@@ -427,9 +427,9 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         case NPM_TUNE_CONV_WGRAD_BLOCKS: return npm_conv_set_wgrad_blocks(value);
         case NPM_TUNE_GEMM_MATH:
-            if (value < 0 || value > 2) return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: NPM_TUNE_GEMM_MATH takes 0, 1 or 2");
+            if (value < 0 || value > 3) return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: NPM_TUNE_GEMM_MATH takes 0, 1, 2 or 3");
             g_math = value;
-            return npm_conv_set_math(value);
+            return npm_conv_set_math(value == 3 ? 2 : value);        // the conv kernels have no f16 form: the bf16 split
         case NPM_TUNE_GEMM_WAVE_PRIO: g_wave_prio = value; return npm_conv_set_wave_prio(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
@@ -501,7 +501,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.group_m = g_group_m;
     a.ablate = g_ablate;
     a.e.prio = g_wave_prio;
-    a.math = g_math;
+    a.math = g_math == 3 ? 2 : g_math;          // NPM_MATH_F16X2 where its kernel does not apply: the bf16 split
     a.trace = g_trace;
 
     const long batch = (long)g->batch0 * g->batch1;
@@ -514,7 +514,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
-        splits = pick_splits(tiles, nkt, npm::ctx().num_cus, 0, g_math == 2 ? 2 : g_math == 1 ? 3 : 4);
+        splits = pick_splits(tiles, nkt, npm::ctx().num_cus, 0, g_math >= 2 ? 2 : g_math == 1 ? 3 : 4);
     }
     if (!linear_epi) splits = 1;
     if (splits > nkt) splits = nkt > 0 ? nkt : 1;
@@ -548,7 +548,9 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     const bool dma_path = dma && a.e.buf_ok;
     // Column sums of B beside a TN product: in the kernel when the LDS-DMA path runs, else a pass over B.
     npm::Scratch bs_part;
-    const bool ksum_fused = want_ksum && dma_path && !a_kmaj && !b_kmaj && g->k > 0;
+    // NPM_MATH_F16X2: one product (no batch), the LDS-DMA path's alignment rules, no epilogue column sums
+    const bool f16x2 = g_math == 3 && dma_path && batch == 1 && !a.wide && !want_colsum && g->k > 0 && !a.ablate && !a.trace;
+    const bool ksum_fused = want_ksum && dma_path && !a_kmaj && !b_kmaj && g->k > 0 && !f16x2;
     const long ksum_rows = (long)splits * std::min(want_bsum ? a.tiles_m : a.tiles_n, GK);
     if (ksum_fused) {
         a.ksum_op = want_bsum ? 1 : 2;
@@ -563,10 +565,35 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
         if (rc) return rc;
         a.e.cs = (float *)cs_part.ptr;
     }
-    if (a_kmaj && b_kmaj) launch<true, true>(a, vec, dma, (int)grid, stream);
-    else if (a_kmaj && !b_kmaj) launch<true, false>(a, vec, dma, (int)grid, stream);
-    else launch<false, false>(a, vec, dma, (int)grid, stream);
-    NPM_CHECK_LAUNCH();
+    npm::Scratch scales;
+    if (f16x2) {
+        // maxima along K of both operands -> power-of-two scales (one pass over each), then the product
+        const size_t mn = (size_t)g->m + (size_t)g->n;
+        int rc = scales.alloc(3 * sizeof(float) * mn);
+        if (rc) return rc;
+        float *sa = (float *)scales.ptr, *sb = sa + g->m, *ia = sb + g->n, *ib = ia + g->m;
+        unsigned *ua = (unsigned *)(ib + g->n), *ub = ua + g->m;
+        rc = npm_tile::f16x2_scales(g->a, g->lda, a_kmaj, g->m, g->k, ua, sa, ia, stream);
+        if (rc) return rc;
+        rc = npm_tile::f16x2_scales(g->b, g->ldb, b_kmaj, g->n, g->k, ub, sb, ib, stream);
+        if (rc) return rc;
+        npm_tile::F16x2Args f{};
+        f.A = g->a; f.B = g->b; f.lda = g->lda; f.ldb = g->ldb;
+        f.M = g->m; f.N = g->n; f.K = g->k;
+        f.a_kmaj = a_kmaj; f.b_kmaj = b_kmaj;
+        f.tiles_m = a.tiles_m; f.tiles_n = a.tiles_n; f.group_m = a.group_m;
+        f.splits = a.splits; f.k_per_split = a.k_per_split; f.slab = a.slab;
+        f.sa = sa; f.sb = sb; f.inv_sa = ia; f.inv_sb = ib;
+        f.e = a.e;
+        npm::note_math(3);
+        rc = npm_tile::launch_f16x2(f, stream);
+        if (rc) return rc;
+    } else {
+        if (a_kmaj && b_kmaj) launch<true, true>(a, vec, dma, (int)grid, stream);
+        else if (a_kmaj && !b_kmaj) launch<true, false>(a, vec, dma, (int)grid, stream);
+        else launch<false, false>(a, vec, dma, (int)grid, stream);
+        NPM_CHECK_LAUNCH();
+    }
 
     if (want_ksum) {
         int rc = NPM_OK;

@@ -615,4 +615,21 @@ struct ReduceArgs {
 
 int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream);
 
+// fp32 GEMM on the f16 matrix pipe, two-way split with row scaling (npm_gemm_f16x2.hip; NPM_MATH_F16X2).  One product, no
+// batch: C[M, N] = op(A) op(B) with the epilogue / split-K machinery of the other kernels.
+struct F16x2Args {
+    const float *A, *B;
+    long lda, ldb;
+    int M, N, K;
+    int a_kmaj, b_kmaj;      // A stored [M][K] (else [K][M]); B stored [N][K] (else [K][N])
+    int tiles_m, tiles_n, group_m, splits, k_per_split;
+    long slab;
+    const float *sa, *sb, *inv_sa, *inv_sb;      // scales along M and N (f16x2_scales) and their reciprocals
+    Epilogue e;
+};
+// scale[i] = 2^(14 - e_i) where the largest magnitude along K of row / column i is f 2^e_i, and inv[i] = 1 / scale[i];
+// `umax` is scratch of `extent` words.  kmaj: x is [extent][k] (pitch ld), else [k][extent].
+int f16x2_scales(const float *x, long ld, bool kmaj, long extent, long k, unsigned *umax, float *scale, float *inv, hipStream_t stream);
+int launch_f16x2(const F16x2Args &a, hipStream_t stream);
+
 }  // namespace npm_tile

@@ -41,7 +41,7 @@ def assert_close(got, ref, tol=1e-5, what=''):
     np.testing.assert_allclose(got, ref, rtol=tol, atol=tol * scale + 1e-30, err_msg=what)
 
 
-MATH_MODES = ['f32', 'bf16x3', 'bf16x3_fast']
+MATH_MODES = ['f32', 'bf16x3', 'bf16x3_fast', 'f16x2']
 
 
 @pytest.fixture(params=MATH_MODES)
