@@ -52,3 +52,12 @@ def math_mode(request):
     np_modeling_amd.set_math(request.param)
     yield request.param
     np_modeling_amd.set_math('f32')
+
+
+@pytest.fixture(autouse=True)
+def _math_mode_back_to_default():
+    """Whatever arithmetic a test selected (and however it ended), the next test starts from 'f32'."""
+    yield
+    from np_modeling_amd import _C
+    if _C._LIB is not None and _C.current_math() != 'f32':
+        _C.set_math('f32')

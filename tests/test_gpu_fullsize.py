@@ -27,7 +27,7 @@ def npm():
     return np_modeling_amd
 
 
-@pytest.fixture(params=['f32', 'bf16x3'])
+@pytest.fixture(params=['f32', 'bf16x3', 'f16x2'])
 def exact_modes(request, npm):
     """The full-size identities hold at the same tolerances under the exact-f32 MFMA and under the unbiased
     split-bf16 mode ('bf16x3_fast' drifts by its documented bias in the 4096-term checksums)."""

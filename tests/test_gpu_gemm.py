@@ -257,12 +257,73 @@ def test_split_math_error_statistics(D):
     assert stats['bf16x3_fast'][1] <= 1.05 * stats['f32'][1] and abs(stats['bf16x3_fast'][0]) < 1.0 * ulp
 
 
+def test_f16x2_error_contract(D):
+    """NPM_MATH_F16X2 (csrc/npm_gemm_f16x2.hip): fp32-class error ROW-NORMWISE.  Against fp64 at K = 4096 the error of an
+    output element relative to the largest element of its output row stays below the exact-f32 MFMA's, for N(0,1) rows,
+    for rows whose magnitudes differ by 2^40 and for elements 2^30 apart inside a row; zero rows give exact zeros; a nan
+    or an inf poisons exactly its own output row (A) or column (B)."""
+    import np_modeling_amd as npm
+    rng = np.random.default_rng(0)
+    m, n, k = 256, 384, 4096
+    b = (rng.standard_normal((k, n), dtype=np.float32) / 64).astype(np.float32)
+    db = D.from_host(b)
+
+    def rel_rms(a, mode):
+        npm.set_math(mode)
+        c = D.empty([m, n])
+        D.gemm(m, n, k, D.Mat(D.from_host(a), k), D.Mat(db, n), D.Mat(c, n))
+        assert npm.last_math() == mode
+        ref = a.astype(np.float64) @ b.astype(np.float64)
+        err = (c.numpy().astype(np.float64) - ref) / np.abs(ref).max(axis=1, keepdims=True)
+        return np.sqrt((err ** 2).mean()), np.abs(err).max(), err.mean()
+
+    try:
+        base = rng.standard_normal((m, k), dtype=np.float32)
+        rows = (base * np.exp2(rng.integers(-20, 21, size=(m, 1)))).astype(np.float32)          # rows 2^40 apart
+        cols = (base * np.exp2(-rng.integers(0, 31, size=(1, k)))).astype(np.float32)           # elements 2^30 apart
+        for name, a in (('gaussian', base), ('row spread', rows), ('element spread', cols)):
+            f32, f16 = rel_rms(a, 'f32'), rel_rms(a, 'f16x2')
+            assert f16[0] <= f32[0] and f16[1] <= 1.5 * f32[1] and abs(f16[2]) < 2e-8, (name, f32, f16)
+        # zero rows / columns, exactly
+        npm.set_math('f16x2')
+        a = base.copy()
+        a[5] = 0.0
+        c = D.empty([m, n])
+        D.gemm(m, n, k, D.Mat(D.from_host(a), k), D.Mat(db, n), D.Mat(c, n))
+        assert np.all(c.numpy()[5] == 0.0) and np.isfinite(c.numpy()).all()
+        # non-finite operands: their own row / column, nothing else
+        a = base.copy()
+        a[7, 100] = np.nan
+        a[9, 200] = np.inf
+        bb = b.copy()
+        bb[300, 11] = np.inf
+        D.gemm(m, n, k, D.Mat(D.from_host(a), k), D.Mat(D.from_host(bb), n), D.Mat(c, n))
+        out = c.numpy()
+        bad = ~np.isfinite(out)
+        want = np.zeros_like(bad)
+        want[7] = want[9] = True
+        want[:, 11] = True
+        np.testing.assert_array_equal(bad, want)
+        # launches it does not cover run (and report) the bf16 split
+        a3 = D.from_host(rng.standard_normal((2, 128, 64)).astype(np.float32))
+        b3 = D.from_host(rng.standard_normal((2, 64, 128)).astype(np.float32))
+        c3 = D.empty([2, 128, 128])
+        D.gemm(128, 128, 64, D.Mat(a3, 64, 128 * 64), D.Mat(b3, 128, 64 * 128), D.Mat(c3, 128, 128 * 128), batch=(2, 1))
+        assert npm.last_math() == 'bf16x3'
+        np.testing.assert_allclose(c3.numpy(), np.einsum('zmk,zkn->zmn', a3.numpy().astype(np.float64), b3.numpy().astype(np.float64)), rtol=0, atol=2e-4)
+    finally:
+        npm.set_math('f32')
+
+
+@pytest.mark.parametrize('sweep_math', ['f32', 'f16x2'])
 @pytest.mark.parametrize('seed', range(6))
-def test_random_sweep(D, seed):
+def test_random_sweep(D, seed, sweep_math):
     """Randomised descriptors against NumPy fp64: layouts, sizes on and off the tile / DMA boundaries, padded and
     unaligned row pitches, two batch dimensions with head-style strides ([b0, rows, b1, cols] storage), every
     epilogue the ABI accepts, split-K requests, the operand column sums; guard words around C and the padding
     columns inside it check that nothing else is written."""
+    import np_modeling_amd as npm
+    npm.set_math(sweep_math)           # 'f16x2': its kernel where it applies (single products, aligned, K % 16 == 0), the bf16 split or the f32 fallback elsewhere
     rng = np.random.default_rng(1000 + seed)
     sizes = [1, 2, 3, 5, 16, 17, 31, 32, 33, 48, 64, 65, 100, 127, 128, 129, 160, 200, 256, 272, 384]
     guard = 5
