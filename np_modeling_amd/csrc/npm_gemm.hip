@@ -573,9 +573,10 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
         if (rc) return rc;
         float *sa = (float *)scales.ptr, *sb = sa + g->m, *ia = sb + g->n, *ib = ia + g->m;
         unsigned *ua = (unsigned *)(ib + g->n), *ub = ua + g->m;
-        rc = npm_tile::f16x2_scales(g->a, g->lda, a_kmaj, g->m, g->k, ua, sa, ia, stream);
+        // the bias gradient beside a weight gradient (asum / bsum: column sums of an MN-major operand) rides the same pass
+        rc = npm_tile::f16x2_scales(g->a, g->lda, a_kmaj, g->m, g->k, ua, sa, ia, stream, want_asum ? g->asum : nullptr);
         if (rc) return rc;
-        rc = npm_tile::f16x2_scales(g->b, g->ldb, b_kmaj, g->n, g->k, ub, sb, ib, stream);
+        rc = npm_tile::f16x2_scales(g->b, g->ldb, b_kmaj, g->n, g->k, ub, sb, ib, stream, want_bsum ? g->bsum : nullptr);
         if (rc) return rc;
         npm_tile::F16x2Args f{};
         f.A = g->a; f.B = g->b; f.lda = g->lda; f.ldb = g->ldb;
@@ -595,7 +596,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
         NPM_CHECK_LAUNCH();
     }
 
-    if (want_ksum) {
+    if (want_ksum && !f16x2) {
         int rc = NPM_OK;
         if (!ksum_fused) rc = want_bsum ? npm::colsum_launch(g->b, g->bsum, g->k, g->n, g->ldb)
                                         : npm::colsum_launch(g->a, g->asum, g->k, g->m, g->lda);

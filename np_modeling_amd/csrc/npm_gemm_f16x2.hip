@@ -59,24 +59,34 @@ rowmax_kernel(const float *__restrict__ x, long ld, long rows, long k, unsigned 
 
 // MN-major operand [k][cols] (row pitch ld): blocks of 64 lanes x 4 columns x 4 row lanes over chunks of rows; the
 // bit patterns of non-negative floats order like unsigned integers, so atomicMax gives the same result in any order
+// SUMS: the same pass also leaves the column sums of its chunk in part[chunk][cols] (the bias gradient that goes with a
+// weight gradient, mlp.py:34): summed per thread in row order, across the four row lanes in lane order, and across the
+// chunks by the ordinary fixed-order column sum -- reproducible.
+template <bool SUMS>
 __global__ void __launch_bounds__(256)
-colmax_kernel(const float *__restrict__ x, long ld, long krows, long cols, long rows_per_chunk, unsigned *__restrict__ umax, int vec) {
+colmax_kernel(const float *__restrict__ x, long ld, long krows, long cols, long rows_per_chunk, unsigned *__restrict__ umax, int vec,
+              float *__restrict__ part) {
     __shared__ float red[4][256];
     const int cq = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const long c0 = (long)blockIdx.x * 256 + cq * 4;
     const long r_beg = (long)blockIdx.y * rows_per_chunk, r_end = min(krows, r_beg + rows_per_chunk);
-    float m[4] = {0.f, 0.f, 0.f, 0.f};
+    float m[4] = {0.f, 0.f, 0.f, 0.f}, s[4] = {0.f, 0.f, 0.f, 0.f};
     if (vec && c0 + 3 < cols) {
         for (long r = r_beg + rl; r < r_end; r += 4) {
             const float4 v = *reinterpret_cast<const float4 *>(x + r * ld + c0);
             m[0] = fmaxf(m[0], fabsf(v.x)); m[1] = fmaxf(m[1], fabsf(v.y));
             m[2] = fmaxf(m[2], fabsf(v.z)); m[3] = fmaxf(m[3], fabsf(v.w));
+            if (SUMS) { s[0] += v.x; s[1] += v.y; s[2] += v.z; s[3] += v.w; }
         }
     } else {
         for (long r = r_beg + rl; r < r_end; r += 4)
 #pragma unroll
             for (int j = 0; j < 4; ++j)
-                if (c0 + j < cols) m[j] = fmaxf(m[j], fabsf(x[r * ld + c0 + j]));
+                if (c0 + j < cols) {
+                    const float v = x[r * ld + c0 + j];
+                    m[j] = fmaxf(m[j], fabsf(v));
+                    if (SUMS) s[j] += v;
+                }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = m[j];
@@ -85,6 +95,13 @@ colmax_kernel(const float *__restrict__ x, long ld, long krows, long cols, long 
     if (c < cols) {
         const float v = fmaxf(fmaxf(red[0][threadIdx.x], red[1][threadIdx.x]), fmaxf(red[2][threadIdx.x], red[3][threadIdx.x]));
         atomicMax(umax + c, __float_as_uint(v));
+    }
+    if (SUMS) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) red[rl][cq * 4 + j] = s[j];
+        __syncthreads();
+        if (c < cols) part[(long)blockIdx.y * cols + c] = ((red[0][threadIdx.x] + red[1][threadIdx.x]) + red[2][threadIdx.x]) + red[3][threadIdx.x];
     }
 }
 
@@ -268,8 +285,11 @@ sgemm_f16x2_kernel(const F16x2Args p) {
 
 namespace npm_tile {
 
-int f16x2_scales(const float *x, long ld, bool kmaj, long extent, long k, unsigned *umax, float *scale, float *inv, hipStream_t stream) {
+int f16x2_scales(const float *x, long ld, bool kmaj, long extent, long k, unsigned *umax, float *scale, float *inv, hipStream_t stream,
+                 float *colsum_out) {
     if (extent <= 0) return NPM_OK;
+    NPM_ARG(colsum_out == nullptr || !kmaj);
+    npm::Scratch part;
     const int vec = (((uintptr_t)x & 15) == 0 && ld % 4 == 0 && (kmaj ? k % 4 == 0 : true)) ? 1 : 0;
     if (kmaj) {
         NPM_ARG((extent + 3) / 4 < (1L << 31));
@@ -281,7 +301,16 @@ int f16x2_scales(const float *x, long ld, bool kmaj, long extent, long k, unsign
         const long rpc = (k + chunks - 1) / chunks;
         chunks = (k + rpc - 1) / rpc;
         NPM_ARG(strips < (1L << 31) && chunks < 65536);
-        if (k > 0) hipLaunchKernelGGL(colmax_kernel, dim3((int)strips, (int)chunks), dim3(256), 0, stream, x, ld, k, extent, rpc, umax, vec);
+        if (colsum_out) {
+            int rc = part.alloc(sizeof(float) * (size_t)chunks * extent);
+            if (rc) return rc;
+            hipLaunchKernelGGL(colmax_kernel<true>, dim3((int)strips, (int)chunks), dim3(256), 0, stream, x, ld, k, extent, rpc, umax, vec, (float *)part.ptr);
+            NPM_CHECK_LAUNCH();
+            rc = npm::colsum_launch((const float *)part.ptr, colsum_out, chunks, extent, extent);
+            if (rc) return rc;
+        } else if (k > 0) {
+            hipLaunchKernelGGL(colmax_kernel<false>, dim3((int)strips, (int)chunks), dim3(256), 0, stream, x, ld, k, extent, rpc, umax, vec, (float *)nullptr);
+        }
     }
     NPM_CHECK_LAUNCH();
     hipLaunchKernelGGL(scales_kernel, dim3((int)((extent + 255) / 256)), dim3(256), 0, stream, umax, scale, inv, extent);

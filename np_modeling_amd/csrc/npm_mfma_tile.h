@@ -629,7 +629,9 @@ struct F16x2Args {
 };
 // scale[i] = 2^(14 - e_i) where the largest magnitude along K of row / column i is f 2^e_i, and inv[i] = 1 / scale[i];
 // `umax` is scratch of `extent` words.  kmaj: x is [extent][k] (pitch ld), else [k][extent].
-int f16x2_scales(const float *x, long ld, bool kmaj, long extent, long k, unsigned *umax, float *scale, float *inv, hipStream_t stream);
+// colsum_out (MN-major operands only): also out[i] = sum over k of column i, from the same pass.
+int f16x2_scales(const float *x, long ld, bool kmaj, long extent, long k, unsigned *umax, float *scale, float *inv, hipStream_t stream,
+                 float *colsum_out = nullptr);
 int launch_f16x2(const F16x2Args &a, hipStream_t stream);
 
 }  // namespace npm_tile

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Signed error of the two GEMM math modes (f32 MFMA / bf16 three-way split) against fp64: mean and rms of (C - ref)."""
+"""Signed error of the GEMM math modes (0 f32 MFMA, 1 / 2 bf16 three-way split with one / two accumulators, 3 scaled
+two-way fp16 split) against fp64: mean and rms of (C - ref), plus rows and elements of widely different magnitude."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -22,8 +23,12 @@ cases['gaussian'] = (a, b)
 tb = lambda x: (x.view(np.uint32) & np.uint32(0xffff0000)).view(np.float32)
 cases['bf16-exact inputs'] = (tb(a.copy()), tb(b.copy()))
 cases['positive'] = (np.abs(a), np.abs(b))
+cases['rows of A 2^40 apart'] = ((a * np.exp2(rng.integers(-20, 21, size=(m, 1)))).astype(np.float32), b)
+cases['elements 2^30 apart'] = ((a * np.exp2(-rng.integers(0, 31, size=(1, k)))).astype(np.float32), b)
 for name, (a, b) in cases.items():
     ref = a.astype(np.float64) @ b.astype(np.float64)
-    for math in (0, 1, 2):
+    rowmax = np.abs(ref).max(axis=1, keepdims=True)
+    for math in (0, 1, 2, 3):
         err = run(a, b, math) - ref
-        print(f'{name:20s} math={math}: mean err {err.mean():+.3e}  rms {np.sqrt((err**2).mean()):.3e}  max|ref| {np.abs(ref).max():.3g}  mean err / ulp(1) {err.mean() / 2**-23:+.3f}')
+        print(f'{name:24s} math={math}: mean err {err.mean():+.3e}  rms {np.sqrt((err**2).mean()):.3e}  max|ref| {np.abs(ref).max():.3g}  mean err / ulp(1) {err.mean() / 2**-23:+.3f}'
+              f'  | relative to the output row maximum: rms {np.sqrt(((err / rowmax)**2).mean()):.3e} worst {np.abs(err / rowmax).max():.3e}')

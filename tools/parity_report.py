@@ -50,7 +50,7 @@ def init(rng, shape, scale=1.0):
 
 
 def main():
-    for mode in ('f32', 'bf16x3'):
+    for mode in ('f32', 'bf16x3', 'f16x2'):
         npm.set_math(mode)
         rng = np.random.default_rng(0)
         # C1 / C2: Dense + ReLU

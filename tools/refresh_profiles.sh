@@ -10,15 +10,17 @@ cd "$REPO"
 echo "== bench (default command)"; timeout -k 10 400 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err" || exit 1
 echo "== clock / power during 60 steps"; tools/clock_sampler.sh "$OUT/clocks_f32.log" -- timeout -k 10 200 python bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-alt-math > "$OUT/bench_60.json" 2>/dev/null
 tools/clock_sampler.sh "$OUT/clocks_bf16x3.log" -- timeout -k 10 200 python bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-alt-math --math bf16x3 > "$OUT/bench_60_bf16x3.json" 2>/dev/null
+tools/clock_sampler.sh "$OUT/clocks_f16x2.log" -- timeout -k 10 200 python bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-alt-math --math f16x2 > "$OUT/bench_60_f16x2.json" 2>/dev/null
 { echo "bench.py --steps 60 --warmup 3, sysfs freq1_input / power1_input of the loaded card (tools/clock_sampler.sh)";
-  for m in f32 bf16x3; do f=$OUT/bench_60.json; [ $m = bf16x3 ] && f=$OUT/bench_60_bf16x3.json;
+  for m in f32 bf16x3 f16x2; do f=$OUT/bench_60.json; [ $m != f32 ] && f=$OUT/bench_60_$m.json;
     echo "math $m: $(python3 -c "import json;d=json.load(open('$f'));print(round(d['value'],1),'samples/s',round(d['ms_per_step'],2),'ms/step')")  $(python3 tools/clock_summary.py $OUT/clocks_$m.log)"; done; } > "$OUT/${R}_clock_power.log"
-echo "== config bench"; { for m in f32 bf16x3 bf16x3_fast; do echo "NPM_MATH=$m"; NPM_MATH=$m timeout -k 10 300 python tools/config_bench.py --kernels; done; } > "$OUT/${R}_config_bench.log" 2>&1
-echo "== gemm shapes"; { for t in 10=0 10=2 10=1; do timeout -k 10 200 python tools/gemm_bench.py --tune $t; done; } > "$OUT/${R}_gemm_shapes.log" 2>&1
+echo "== config bench"; { for m in f32 bf16x3 bf16x3_fast f16x2; do echo "NPM_MATH=$m"; NPM_MATH=$m timeout -k 10 300 python tools/config_bench.py --kernels; done; } > "$OUT/${R}_config_bench.log" 2>&1
+echo "== gemm shapes"; { for t in 10=0 10=2 10=1 10=3; do timeout -k 10 200 python tools/gemm_bench.py --tune $t; done; } > "$OUT/${R}_gemm_shapes.log" 2>&1
 echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/${R}_rowops.log" 2>&1
 echo "== math error"; timeout -k 10 100 python tools/math_bias.py > "$OUT/${R}_math_error.log" 2>&1
 echo "== fused attention core"; { timeout -k 10 100 python tools/attn_bench.py; timeout -k 10 100 python tools/attn_bench.py --save-scores; echo "-- stamps, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved (the default)"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
 echo "== GEMM block timelines"; { for sh in "131072 1024 1024" "131072 4096 1024" "131072 1024 4096" "3211264 128 576" c2; do timeout -k 10 100 python tools/gemm_trace.py $sh 2>&1 | grep -E "^K=|^in us|^traced|^matrix pipe"; done; } > "$OUT/${R}_gemm_timeline.log" 2>&1
+echo "== scaled fp16 split prototype"; ( cd tools/microbench && { [ -x f16x2_gemm ] || hipcc -O3 --offload-arch=gfx950 f16x2_gemm.hip -o f16x2_gemm; } && timeout -k 10 300 ./f16x2_gemm ) > "$OUT/${R}_f16x2_gemm.log" 2>&1
 echo "== split-bf16 prototype and ablations"; ( cd tools/microbench && { [ -x coop_split_gemm ] || hipcc -O3 --offload-arch=gfx950 coop_split_gemm.hip -o coop_split_gemm; } && timeout -k 10 200 ./coop_split_gemm ) > "$OUT/${R}_coop_split_gemm.log" 2>&1
 echo "== f32 MFMA issue microbenchmark"; timeout -k 10 60 tools/microbench/mfma_f32_chain > "$OUT/${R}_mfma_f32_chain.log" 2>&1
 echo "== parity report"; timeout -k 10 600 python tools/parity_report.py > "$OUT/${R}_parity_relative_error.log" 2>&1
