@@ -621,6 +621,29 @@ def dropout_philox_mask(n: int, keep_prob: float, seed: int, offset: int) -> Arr
     return words.astype(np.uint64) < np.uint64(threshold)
 
 
+def f16x2_scales(x: Array, axis: int):
+    """Power-of-two scales of the product's scaled fp16 split (np_modeling_amd/csrc/npm_gemm_f16x2.hip scales_kernel):
+    2^(14 - e) where the largest magnitude along `axis` is f 2^e with f in [0.5, 1); 1 for an all-zero slice.  Not a
+    restatement of the reference (which has no such mode): the arithmetic of the product's OWN opt-in math mode,
+    spelled out so that tests can hold the kernel to it."""
+    m = np.abs(np.asarray(x, dtype=np.float32)).max(axis=axis, keepdims=True)
+    _, e = np.frexp(m)
+    return np.where(m > 0, np.ldexp(np.float32(1), np.clip(14 - e, -100, 100)), np.float32(1)).astype(np.float32)
+
+
+def gemm_f16x2(a: Array, b: Array) -> Array:
+    """C = A B as NPM_MATH_F16X2 forms it: rows of A and columns of B scaled by powers of two, x s = hi + lo with hi =
+    fp16(x s) rounded to nearest and lo = fp16(x s - hi), C = (hi hi + hi lo + lo hi) / (s_a s_b).  The three products
+    are accumulated in fp64 here (the kernel accumulates them in fp32 on the matrix pipe)."""
+    a, b = np.asarray(a, dtype=np.float32), np.asarray(b, dtype=np.float32)
+    sa, sb = f16x2_scales(a, 1), f16x2_scales(b, 0)
+    xa, xb = a * sa, b * sb                                   # exact: powers of two
+    ha, hb = xa.astype(np.float16), xb.astype(np.float16)
+    la, lb = (xa - ha.astype(np.float32)).astype(np.float16), (xb - hb.astype(np.float32)).astype(np.float16)
+    ha, hb, la, lb = (t.astype(np.float64) for t in (ha, hb, la, lb))
+    return (ha @ hb + (ha @ lb + la @ hb)) / (sa.astype(np.float64) * sb.astype(np.float64))
+
+
 def sgd_step(param: Array, grad: Array, lr: float) -> Array:
     """v -= lr * g, in the parameter's own dtype (optimizer.py:32)."""
     out = param.copy()

@@ -263,6 +263,7 @@ def test_f16x2_error_contract(D):
     for rows whose magnitudes differ by 2^40 and for elements 2^30 apart inside a row; zero rows give exact zeros; a nan
     or an inf poisons exactly its own output row (A) or column (B)."""
     import np_modeling_amd as npm
+    from oracle import np_oracle as O
     rng = np.random.default_rng(0)
     m, n, k = 256, 384, 4096
     b = (rng.standard_normal((k, n), dtype=np.float32) / 64).astype(np.float32)
@@ -284,8 +285,15 @@ def test_f16x2_error_contract(D):
         for name, a in (('gaussian', base), ('row spread', rows), ('element spread', cols)):
             f32, f16 = rel_rms(a, 'f32'), rel_rms(a, 'f16x2')
             assert f16[0] <= f32[0] and f16[1] <= 1.5 * f32[1] and abs(f16[2]) < 2e-8, (name, f32, f16)
-        # zero rows / columns, exactly
+        # the kernel against the NumPy restatement of its arithmetic (same scales, same fp16 parts; fp64 sums there, fp32
+        # sums on the matrix pipe here): what is left is accumulation order
         npm.set_math('f16x2')
+        c = D.empty([m, n])
+        D.gemm(m, n, k, D.Mat(D.from_host(rows), k), D.Mat(db, n), D.Mat(c, n))
+        want = O.gemm_f16x2(rows, b)
+        dev = (c.numpy().astype(np.float64) - want) / np.abs(want).max(axis=1, keepdims=True)
+        assert np.sqrt((dev ** 2).mean()) < 1.5e-7 and np.abs(dev).max() < 1.5e-6, (np.sqrt((dev ** 2).mean()), np.abs(dev).max())
+        # zero rows / columns, exactly
         a = base.copy()
         a[5] = 0.0
         c = D.empty([m, n])
