@@ -105,8 +105,9 @@ colmax_kernel(const float *__restrict__ x, long ld, long krows, long cols, long 
     }
 }
 
-// s = 2^(14 - e) with max = f 2^e, f in [0.5, 1): max s in [2^13, 2^14).  Clamped so that s and 1 / s stay normal fp32;
-// an all-zero row gets 1.
+// s = 2^(14 - e) with max = f 2^e, f in [0.5, 1): max s in [2^13, 2^14).  The exponent is cut at 126 so that s and 1 / s stay
+// normal fp32 (only rows whose maximum is below 2^-112 are scaled short of the target, down to rows of subnormals);
+// the largest finite maximum, e = 128, needs 2^-114.  An all-zero row gets 1.
 __global__ void scales_kernel(const unsigned *__restrict__ umax, float *__restrict__ scale, float *__restrict__ inv, long n) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -115,7 +116,7 @@ __global__ void scales_kernel(const unsigned *__restrict__ umax, float *__restri
     float s = 1.f, r = 1.f;
     if (m > 0.f && m < INFINITY) {
         (void)frexpf(m, &e);
-        const int sh = max(-100, min(100, 14 - e));
+        const int sh = min(126, 14 - e);
         s = ldexpf(1.f, sh);
         r = ldexpf(1.f, -sh);
     } else if (!(m == 0.f)) {                        // inf or nan anywhere in the row: poison it

@@ -628,7 +628,7 @@ def f16x2_scales(x: Array, axis: int):
     spelled out so that tests can hold the kernel to it."""
     m = np.abs(np.asarray(x, dtype=np.float32)).max(axis=axis, keepdims=True)
     _, e = np.frexp(m)
-    return np.where(m > 0, np.ldexp(np.float32(1), np.clip(14 - e, -100, 100)), np.float32(1)).astype(np.float32)
+    return np.where(m > 0, np.ldexp(np.float32(1), np.minimum(14 - e, 126)), np.float32(1)).astype(np.float32)
 
 
 def gemm_f16x2(a: Array, b: Array) -> Array:

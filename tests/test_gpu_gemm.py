@@ -293,6 +293,14 @@ def test_f16x2_error_contract(D):
         want = O.gemm_f16x2(rows, b)
         dev = (c.numpy().astype(np.float64) - want) / np.abs(want).max(axis=1, keepdims=True)
         assert np.sqrt((dev ** 2).mean()) < 1.5e-7 and np.abs(dev).max() < 1.5e-6, (np.sqrt((dev ** 2).mean()), np.abs(dev).max())
+        # magnitudes at both ends of the fp32 range: the scales stay normal numbers, nothing overflows in fp16
+        ext = base.copy()
+        ext[0::2] *= np.float32(2.0 ** 110)
+        ext[1::2] *= np.float32(2.0 ** -120)
+        D.gemm(m, n, k, D.Mat(D.from_host(ext), k), D.Mat(db, n), D.Mat(c, n))
+        ref = ext.astype(np.float64) @ b.astype(np.float64)
+        dev = np.abs(c.numpy().astype(np.float64) - ref) / np.abs(ref).max(axis=1, keepdims=True)
+        assert np.isfinite(c.numpy()).all() and dev.max() < 2e-6, dev.max()
         # zero rows / columns, exactly
         a = base.copy()
         a[5] = 0.0
