@@ -35,6 +35,11 @@ import numpy as np  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2516.6     # same guide: v_mfma_f32_32x32x16_bf16, dense (16x the f32 MFMA rate)
 HBM_PEAK_GBS = 8000.0
+MATH_NOTE = {     # what a non-default --math does to the matrix products (include/npm_hip.h NPM_MATH_*)
+    'bf16x3': 'products as six v_mfma_f32_32x32x16_bf16 of three-way bf16-split operands',
+    'bf16x3_fast': 'products as six v_mfma_f32_32x32x16_bf16 of three-way bf16-split operands, one accumulator',
+    'f16x2': 'products as three v_mfma_f32_32x32x16_f16 of row-scaled two-way fp16-split operands (the bf16 split for batched products)',
+}
 MFMA_BOUND = ('sgemm_', 'mha_core_')    # kernel-timer names of the MFMA-bound family: GEMMs and the fused attention core
 
 
@@ -165,6 +170,9 @@ def main():
     ap.add_argument('--cpu-steps', type=int, default=3)
     ap.add_argument('--cpu-verbatim-seq', type=int, default=256, help='tokens of the reference-verbatim CPU sample (0 = skip)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-configs', action='store_true',
+                    help="skip the 'configs' object (BASELINE.json configs[1..3] = C2 Dense, C3 Conv2D, C4 MHA at full size, N = 1 only)")
+    ap.add_argument('--configs-min-seconds', type=float, default=0.5, help='timed seconds per config (tools/config_bench.py rule)')
     ap.add_argument('--no-kernel-timer', action='store_true')
     ap.add_argument('--math', default='f32', choices=['f32', 'bf16x3', 'bf16x3_fast', 'f16x2'],
                     help="arithmetic of the matrix products for the headline measurement (include/npm_hip.h npm_set_math)")
@@ -216,6 +224,10 @@ def main():
     if comm.active:
         comm.barrier()
 
+    rccl = isinstance(comm, parallel.RcclCommunicator)
+    if rccl:
+        comm.stats_enable(True)
+        comm.stats()                                     # drop what the warm-up steps recorded
     timer = None if args.no_kernel_timer else D.KernelTimer()
     if timer is not None:
         timer.__enter__()
@@ -228,6 +240,9 @@ def main():
     elapsed = time.perf_counter() - t0
     if timer is not None:
         timer.__exit__(None, None, None)
+    exchange_stats = comm.stats() if rccl else None
+    if rccl:
+        comm.stats_enable(False)
     if comm.active:
         elapsed = comm.allreduce_scalar(elapsed, parallel.MAX)
 
@@ -240,7 +255,7 @@ def main():
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None,
-        'dtype': 'f32' if args.math == 'f32' else f'f32 ({args.math}: products as six bf16 MFMAs of three-way split operands, fp32 accumulate)',
+        'dtype': 'f32' if args.math == 'f32' else f'f32 ({args.math}: {MATH_NOTE[args.math]}, fp32 accumulate)',
         'math': args.math, 'data': 'synthetic N(0,1) fp32 inputs resident in HBM; random-init '
         'weights (reference initializer scaled by 1/sqrt(fan_in))',
         'config': {'workload': f'TransformerEncoder fwd+bwd+SGD step, d_model={args.features}, heads={args.heads}, '
@@ -254,7 +269,19 @@ def main():
     if comm.active:
         result['exchange'] = {'library': parallel.RcclCommunicator.library_path(), 'reduce': 'avg',
                               'launcher': 'external (RANK/WORLD_SIZE in the environment)' if 'NPM_RENDEZVOUS_FILE' not in os.environ
-                              else 'np_modeling_amd.launch (self-launched child ranks)', 'torch_imported': 'torch' in sys.modules}
+                              else 'np_modeling_amd.launch (self-launched child ranks)', 'torch_imported': 'torch' in sys.modules,
+                              'device': npm._C.device_index(), 'visible_devices': npm._C.visible_devices()}
+        if exchange_stats is not None:
+            # rank 0's view, HIP events (include/npm_comm.h npm_comm_stats): allreduce_ms = time the collectives held the
+            # communication stream (overlaps backward); exposed_ms = time the compute stream stood still waiting for them
+            k = max(args.steps, 1)
+            result['exchange'].update({
+                'bytes_per_step': exchange_stats['bytes'] / k, 'flushes_per_step': exchange_stats['allreduce_calls'] / k,
+                'allreduce_ms': exchange_stats['allreduce_ms'] / k, 'exposed_ms': exchange_stats['exposed_ms'] / k,
+                'exposed_frac_of_step': exchange_stats['exposed_ms'] / (1e3 * elapsed) if elapsed > 0 else None,
+                'busbw_GBps': (2 * (world - 1) / world * exchange_stats['bytes'] / (exchange_stats['allreduce_ms'] * 1e-3) / 1e9
+                               if world > 1 and exchange_stats['allreduce_ms'] > 0 else None),
+                'note': 'per step, rank 0; allreduce_ms overlaps backward, exposed_ms is what the compute stream waited'})
 
     if timer is not None:
         summary = timer.summary()
@@ -267,8 +294,8 @@ def main():
         traffic, traffic_src = load_pmc_traffic(args)
         result['roofline'] = {
             'kernel': ('sgemm_glds_kernel (fp32 v_mfma_f32_32x32x2_f32 GEMM family, LDS-DMA pipeline: NN/NT/TN)' if args.math == 'f32' else
-                       f'sgemm_glds_kernel ({args.math}: six v_mfma_f32_32x32x16_bf16 per fp32 product; achieved counts fp32-equivalent '
-                       'FLOPs against the f32 MFMA peak, the bf16 pipe executes 6x that)'),
+                       f'{"sgemm_f16x2_kernel" if args.math == "f16x2" else "sgemm_glds_kernel"} ({args.math}: {MATH_NOTE[args.math]}; achieved '
+                       'counts fp32-equivalent FLOPs against the f32 MFMA peak, the 16-bit pipe executes 3-6x that)'),
             'bound': 'mfma', 'achieved': achieved, 'peak': FP32_MFMA_PEAK_TFLOPS, 'unit': 'TFLOP/s',
             'frac': achieved / FP32_MFMA_PEAK_TFLOPS, 'traffic': traffic, 'traffic_unit': 'bytes per launch',
             'traffic_source': traffic_src,
@@ -322,7 +349,7 @@ def main():
             'roofline': alt_roofline(alt_timer),
             'note': 'same workload and timing protocol with npm_set_math(NPM_MATH_BF16X3): fp32 inputs/outputs/accumulators, '
                     'each product formed from three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16); '
-                    'rms error vs fp64 at or below the exact-f32 MFMA path (profiles/r01_math_error.log). '
+                    'rms error vs fp64 at or below the exact-f32 MFMA path (profiles/r02_math_error.log). '
                     'Not the headline: value above is the exact-f32 MFMA path.'})
         result['alt_math'] = obj
         # ... and on the f16 pipe: two-way fp16 split with row scaling, three MFMAs per product (csrc/npm_gemm_f16x2.hip)
@@ -336,10 +363,28 @@ def main():
                     'fp64 below a k-ordered fp32 fma chain ROW-NORMWISE (profiles/r02_f16x2_gemm.log), not elementwise. '
                     'Not the headline: value above is the exact-f32 MFMA path.'})
         result['alt_math_f16x2'] = obj
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        result['cpu_baseline'] = cpu_baseline(args, params)
+    if world == 1 and not args.no_configs and args.math == 'f32':
+        # The other single-GPU configurations of BASELINE.json at full size, same process, after the headline regions
+        # (tools/config_bench.py: >= configs_min_seconds timed after half of that as warm-up, fwd+bwd+SGD, exact-f32).
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import config_bench
+        del enc, qkv, dy
+        D.trim_pool()
+        result['configs'] = {}
+        for name in config_bench.NAMES:
+            entry = config_bench.run_config(name, npm, D, min_seconds=args.configs_min_seconds)
+            D.trim_pool()
+            if not args.no_cpu_baseline:
+                entry['cpu_baseline'] = config_bench.cpu_baseline(name)
+            result['configs'][name] = entry
+    if comm.active:
+        comm.barrier()                                   # the ranks stay together until rank 0's CPU sample starts
+    if rank == 0 and not args.no_cpu_baseline:
+        result['cpu_baseline'] = cpu_baseline(args, params)      # rank 0's host cores, after every timed region, any N
     if rank == 0:
         print(json.dumps(result))
+    if comm.active:
+        comm.barrier()                                   # nobody tears the communicator down under rank 0's feet
     parallel.shutdown()
 
 

@@ -40,6 +40,20 @@ int npm_comm_allreduce_f32(float *buf, size_t count, int op);
 int npm_comm_broadcast_f32(float *buf, size_t count, int root);
 /* Make the compute stream wait for every collective issued so far. */
 int npm_comm_wait(void);
+/* Exchange statistics, for bench.py's `exchange` object.  While enabled, every all-reduce is bracketed by timing
+ * events on the communication stream and every npm_comm_wait by timing events on the compute stream;
+ * npm_comm_stats synchronises both streams, returns the sums since the previous call and resets them.
+ *   allreduce_ms  time the collectives occupied the communication stream (they overlap backward)
+ *   exposed_ms    time the compute stream stood still in npm_comm_wait: what the exchange COSTS the step */
+typedef struct npm_comm_exchange_stats {
+    unsigned long long bytes;      /* payload bytes handed to ncclAllReduce */
+    int allreduce_calls;
+    int waits;
+    double allreduce_ms;
+    double exposed_ms;
+} npm_comm_exchange_stats;
+int npm_comm_stats_enable(int on);
+int npm_comm_stats(npm_comm_exchange_stats *out);
 /* Host-blocking: all ranks have reached this point and their GPU work is complete. */
 int npm_comm_barrier(void);
 /* Host scalar reduction (bench.py: max over ranks of the elapsed time). */

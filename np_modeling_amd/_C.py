@@ -70,6 +70,11 @@ class npm_mha_core(C.Structure):
     ]
 
 
+class npm_comm_exchange_stats(C.Structure):
+    _fields_ = [('bytes', C.c_ulonglong), ('allreduce_calls', C.c_int), ('waits', C.c_int),
+                ('allreduce_ms', C.c_double), ('exposed_ms', C.c_double)]
+
+
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK, EPI_RELU, EPI_SOFTMAX_BWD = 1, 2, 4, 8, 16, 32
 
 _P, _SZ, _I64, _I32, _F = C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_float
@@ -143,6 +148,8 @@ COMM_SIGNATURES = {
     'npm_comm_allreduce_f32': [_P, _SZ, C.c_int],
     'npm_comm_broadcast_f32': [_P, _SZ, C.c_int],
     'npm_comm_wait': [],
+    'npm_comm_stats_enable': [C.c_int],
+    'npm_comm_stats': [C.POINTER(npm_comm_exchange_stats)],
     'npm_comm_barrier': [],
     'npm_comm_allreduce_host_f64': [C.POINTER(C.c_double), C.c_int],
     'npm_comm_destroy': [],
@@ -221,7 +228,9 @@ def lib():
     if _LIB is None:
         _LIB = load_library()
     if _DEVICE is None:
-        device = int(os.environ.get('NPM_DEVICE', os.environ.get('LOCAL_RANK', '0')))
+        count = C.c_int(0)
+        _LIB.npm_device_count(C.byref(count))         # 0 devices: npm_init below reports it with the HIP error text
+        device = pick_device(count.value, os.environ)
         rc = _LIB.npm_init(device)
         if rc != 0:
             msg = _LIB.npm_last_error()
@@ -236,15 +245,35 @@ def lib():
     return _LIB
 
 
+def pick_device(visible: int, env) -> int:
+    """Which of the ``visible`` HIP devices this process drives.
+
+    ``NPM_DEVICE`` names it outright.  Otherwise one process per GPU: launchers either show every rank all GPUs of
+    the node (the self-launcher, ``torch.distributed.run``) -- then ``LOCAL_RANK`` is the device index -- or mask
+    the devices per rank (``HIP_VISIBLE_DEVICES`` / ``ROCR_VISIBLE_DEVICES`` = one GPU each) -- then the only
+    visible device, index 0, is this rank's, whatever ``LOCAL_RANK`` says.  A mask that leaves several devices but
+    fewer than ``LOCAL_RANK + 1`` is a launch error and reported as one (two ranks would share a GPU silently)."""
+    if env.get('NPM_DEVICE'):
+        return int(env['NPM_DEVICE'])
+    local = int(env.get('LOCAL_RANK', '0'))
+    if visible <= 1:
+        return 0
+    if local >= visible:
+        raise NpmError(f'LOCAL_RANK={local} but only {visible} HIP devices are visible: show every rank all GPUs of '
+                       'the node, or exactly one each (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), or set NPM_DEVICE')
+    return local
+
+
 MATH_MODES = {'f32': 0, 'bf16x3_fast': 1, 'bf16x3': 2, 'f16x2': 3}      # include/npm_hip.h NPM_MATH_*
 
 
-_MATH = 'f32'
-
-
 def current_math() -> str:
-    """The math mode last set through :func:`set_math` (no library call)."""
-    return _MATH
+    """The math mode the library is in (``npm_get_math``: one cheap call; a mode set through ``NPM_TUNE=10=<mode>``
+    or a direct ``npm_set_tuning`` is seen too).  'f32' before the library is bound."""
+    if _LIB is None or _DEVICE is None:
+        return 'f32'
+    value = _LIB.npm_get_math()
+    return next(name for name, v in MATH_MODES.items() if v == value)
 
 
 def set_math(mode: str) -> None:
@@ -254,9 +283,7 @@ def set_math(mode: str) -> None:
     include/npm_hip.h."""
     if mode not in MATH_MODES:
         raise ValueError(f'unknown math mode {mode!r}: expected one of {sorted(MATH_MODES)}')
-    global _MATH
     check(lib().npm_set_math(MATH_MODES[mode]), 'npm_set_math')
-    _MATH = mode
 
 
 def get_math() -> str:
@@ -291,3 +318,10 @@ def check_comm(rc: int, what: str = '') -> None:
 
 def device_index() -> Optional[int]:
     return _DEVICE
+
+
+def visible_devices() -> int:
+    """HIP devices this process can see (after any HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES mask)."""
+    count = C.c_int(0)
+    (load_library() if _LIB is None else _LIB).npm_device_count(C.byref(count))
+    return count.value

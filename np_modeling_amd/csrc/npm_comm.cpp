@@ -10,6 +10,8 @@
 #include <cstring>
 #include <dlfcn.h>
 #include <unistd.h>
+#include <utility>
+#include <vector>
 
 #include "npm_comm.h"
 
@@ -49,7 +51,23 @@ struct Comm {
     hipEvent_t produced = nullptr;     // compute -> comm
     hipEvent_t reduced = nullptr;      // comm -> compute
     double *scalar = nullptr;          // device scratch for host scalar reductions
+    // exchange statistics (npm_comm_stats_*): timing-enabled event pairs, read back and recycled by npm_comm_stats
+    bool stats = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> reduce_spans;   // on the communication stream, around each all-reduce
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_spans;     // on the compute stream, around each wait
+    std::vector<hipEvent_t> spare;
+    unsigned long long bytes = 0;
+    int calls = 0, waits = 0;
 } g;
+
+int timed_event(hipEvent_t *ev) {
+    if (!g.spare.empty()) {
+        *ev = g.spare.back();
+        g.spare.pop_back();
+        return 0;
+    }
+    return (int)hipEventCreate(ev);
+}
 
 #define HIPC(expr)                                                                  \
     do {                                                                            \
@@ -135,7 +153,19 @@ int npm_comm_allreduce_f32(float *buf, size_t count, int op) {
     if (!buf) return fail(-1, "npm_comm_allreduce_f32: null buffer");
     HIPC(hipEventRecord(g.produced, g.compute));          // gradients written so far ...
     HIPC(hipStreamWaitEvent(g.stream, g.produced, 0));    // ... are visible to the collective
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (g.stats) {
+        HIPC((hipError_t)timed_event(&t0));
+        HIPC((hipError_t)timed_event(&t1));
+        HIPC(hipEventRecord(t0, g.stream));
+    }
     NCCLC(ncclAllReduce(buf, buf, count, ncclFloat32, to_op(op), g.comm, g.stream));
+    if (g.stats) {
+        HIPC(hipEventRecord(t1, g.stream));
+        g.reduce_spans.emplace_back(t0, t1);
+        g.bytes += (unsigned long long)count * sizeof(float);
+        g.calls += 1;
+    }
     return 0;
 }
 
@@ -152,7 +182,56 @@ int npm_comm_broadcast_f32(float *buf, size_t count, int root) {
 int npm_comm_wait(void) {
     REQUIRE_READY();
     HIPC(hipEventRecord(g.reduced, g.stream));
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (g.stats) {
+        HIPC((hipError_t)timed_event(&t0));
+        HIPC((hipError_t)timed_event(&t1));
+        HIPC(hipEventRecord(t0, g.compute));              // the compute stream arrives here ...
+    }
     HIPC(hipStreamWaitEvent(g.compute, g.reduced, 0));
+    if (g.stats) {
+        HIPC(hipEventRecord(t1, g.compute));              // ... and goes on here: the difference is EXPOSED exchange time
+        g.wait_spans.emplace_back(t0, t1);
+        g.waits += 1;
+    }
+    return 0;
+}
+
+int npm_comm_stats_enable(int on) {
+    REQUIRE_READY();
+    g.stats = on != 0;
+    return 0;
+}
+
+int npm_comm_stats(npm_comm_exchange_stats *out) {
+    REQUIRE_READY();
+    if (!out) return fail(-1, "npm_comm_stats: null result");
+    HIPC(hipStreamSynchronize(g.stream));
+    HIPC(hipStreamSynchronize(g.compute));
+    double reduce_ms = 0, exposed_ms = 0;
+    for (auto &span : g.reduce_spans) {
+        float ms = 0;
+        HIPC(hipEventElapsedTime(&ms, span.first, span.second));
+        reduce_ms += ms;
+        g.spare.push_back(span.first);
+        g.spare.push_back(span.second);
+    }
+    for (auto &span : g.wait_spans) {
+        float ms = 0;
+        HIPC(hipEventElapsedTime(&ms, span.first, span.second));
+        exposed_ms += ms;
+        g.spare.push_back(span.first);
+        g.spare.push_back(span.second);
+    }
+    out->bytes = g.bytes;
+    out->allreduce_calls = g.calls;
+    out->waits = g.waits;
+    out->allreduce_ms = reduce_ms;
+    out->exposed_ms = exposed_ms;
+    g.reduce_spans.clear();
+    g.wait_spans.clear();
+    g.bytes = 0;
+    g.calls = g.waits = 0;
     return 0;
 }
 
@@ -182,6 +261,9 @@ int npm_comm_destroy(void) {
     (void)hipFree(g.scalar);
     (void)hipEventDestroy(g.produced);
     (void)hipEventDestroy(g.reduced);
+    for (auto &span : g.reduce_spans) { (void)hipEventDestroy(span.first); (void)hipEventDestroy(span.second); }
+    for (auto &span : g.wait_spans) { (void)hipEventDestroy(span.first); (void)hipEventDestroy(span.second); }
+    for (hipEvent_t ev : g.spare) (void)hipEventDestroy(ev);
     (void)hipStreamDestroy(g.stream);
     g = Comm();
     return 0;

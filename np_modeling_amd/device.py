@@ -380,6 +380,13 @@ def pool_stats() -> Tuple[int, int]:
     return used.value, reserved.value
 
 
+def trim_pool() -> None:
+    """Hand the cached (free) blocks of the pool back to the driver (between workloads of different shapes)."""
+    import gc
+    gc.collect()
+    _C.check(_C.lib().npm_pool_trim(), 'npm_pool_trim')
+
+
 class Event:
     """HIP event on the compute stream (bench.py times kernels with these)."""
 

@@ -10,7 +10,10 @@ np_modeling_amd/parallel.py).  Rules it keeps:
 * the shared libraries are built (if missing) BEFORE the ranks start, so N ranks never race in ``make``;
 * a rank that exits non-zero (or dies on a signal) ends the job: the others are terminated and the launcher
   returns that rank's code;
-* rank 0's stdout is the launcher's stdout (bench.py prints its one JSON line there); all ranks share stderr.
+* rank 0's stdout is the launcher's stdout (bench.py prints its one JSON line there); all ranks share stderr;
+* a launcher that is TERMINATED (SIGTERM / SIGHUP / SIGINT -- ``timeout -k 10 400 python bench.py --gpus N`` sends
+  exactly that) takes its ranks with it: the signal is turned into an exception that runs the clean-up below, and
+  every rank asks the kernel for a SIGTERM of its own should the launcher die without cleaning up (SIGKILL).
 
     python -m np_modeling_amd.launch --gpus 8 train_script.py --its-own --flags
 """
@@ -27,12 +30,31 @@ import time
 from typing import Dict, List, Optional, Sequence
 
 
+class _Terminated(Exception):
+    def __init__(self, signum: int):
+        super().__init__(signum)
+        self.signum = signum
+
+
+def _die_with_parent() -> None:
+    """Child side, between fork and exec: PR_SET_PDEATHSIG(SIGTERM) -- the kernel signals the rank when the launcher
+    thread that started it exits, however it exits (the clean-up of a SIGKILLed launcher)."""
+    import ctypes
+    try:
+        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
+    except Exception:
+        pass
+
+
 def rank_environment(rank: int, world: int, rendezvous_file: str, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
                NPM_RENDEZVOUS_FILE=rendezvous_file)
     env.setdefault('MASTER_ADDR', '127.0.0.1')
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC: RCCL's peer mappings need it on this driver
+    # RCCL maps its peers' buffers through HIP IPC handles; this pool's host driver implements the dmabuf IPC mode
+    # only, and with the legacy mode (the ROCr default) hipIpcGetMemHandle returns "invalid argument" (documented
+    # for this image, which exports the variable itself; DESIGN.md 4.4).  setdefault: an outer setting wins.
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     return env
 
 
@@ -49,10 +71,21 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
     rendezvous = os.path.join(workdir, 'rccl_id')
     procs: List[subprocess.Popen] = []
     code = 0
+
+    def on_signal(signum, frame):
+        raise _Terminated(signum)
+
+    handled = (signal.SIGTERM, signal.SIGHUP)
+    previous = {}
+    try:
+        for sig in handled:
+            previous[sig] = signal.signal(sig, on_signal)
+    except ValueError:                              # not the main thread: the caller owns signal handling
+        previous = {}
     try:
         for rank in range(n):
             procs.append(subprocess.Popen(list(argv), env=rank_environment(rank, n, rendezvous, env),
-                                          stdout=None if rank == 0 else sys.stderr))
+                                          stdout=None if rank == 0 else sys.stderr, preexec_fn=_die_with_parent))
         pending = set(range(n))
         while pending and code == 0:
             for rank in sorted(pending):
@@ -69,7 +102,11 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
                 time.sleep(poll)
     except KeyboardInterrupt:
         code = 130
+    except _Terminated as stop:
+        code = 128 + stop.signum                    # 143 for SIGTERM, like a shell reports it
     finally:
+        for sig in previous:                        # a second signal during the clean-up must not abandon it
+            signal.signal(sig, signal.SIG_IGN)
         for p in procs:                             # exactly the processes started here, by handle
             if p.poll() is None:
                 p.send_signal(signal.SIGTERM)
@@ -81,6 +118,8 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
                 p.kill()
                 p.wait()
         shutil.rmtree(workdir, ignore_errors=True)
+        for sig, handler in previous.items():
+            signal.signal(sig, handler)
     return code
 
 

@@ -30,7 +30,15 @@ class Loss(layer.Layer):
         """Host targets are read afresh at every forward, as the reference does (a caller may refill the same
         array in place between steps); ``Trainer.train`` uploads them once before its loop instead."""
         if isinstance(targets, D.DeviceArray):
-            return targets
+            if tuple(targets.shape) == tuple(shape):
+                return targets
+            # ``y - targets`` broadcasts in the reference (loss.py:24,28): resident targets of another, broadcastable
+            # shape ([B, 1], a scalar) are expanded once per (targets, shape) -- the kernels read y.size elements
+            cached = getattr(self, '_expanded', None)
+            if cached is None or cached[0] is not targets or cached[1] != tuple(shape):
+                wide = np.broadcast_to(np.asarray(targets, dtype=np.float32), shape)    # ValueError if not broadcastable
+                self._expanded = cached = (targets, tuple(shape), D.from_host(wide))
+            return cached[2]
         return D.from_host(np.broadcast_to(np.asarray(targets, dtype=np.float32), shape))
 
 

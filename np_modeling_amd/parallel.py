@@ -106,6 +106,16 @@ class RcclCommunicator(Communicator):
         _C.check_comm(self._lib.npm_comm_broadcast_f32(flat.ptr, flat.size, root), 'npm_comm_broadcast_f32')
         self.wait()
 
+    def stats_enable(self, on: bool = True) -> None:
+        _C.check_comm(self._lib.npm_comm_stats_enable(int(on)), 'npm_comm_stats_enable')
+
+    def stats(self) -> dict:
+        """Exchange statistics since the previous call (include/npm_comm.h npm_comm_stats; synchronises)."""
+        out = _C.npm_comm_exchange_stats()
+        _C.check_comm(self._lib.npm_comm_stats(C.byref(out)), 'npm_comm_stats')
+        return {'bytes': int(out.bytes), 'allreduce_calls': out.allreduce_calls, 'waits': out.waits,
+                'allreduce_ms': out.allreduce_ms, 'exposed_ms': out.exposed_ms}
+
     def close(self):
         self._lib.npm_comm_destroy()
 
@@ -117,55 +127,110 @@ _REDUCE_OP = AVG
 def _launch_token() -> str:
     """Identifies ONE launch of the ranks of this node: they are children of the same launcher process (the
     self-launcher of np_modeling_amd/launch.py, ``torch.distributed.run``'s agent, a shell), so its pid plus its start
-    time (field 22 of /proc/<pid>/stat; pids are recycled, start times are not) is the same for every rank of
-    the launch and different from every other launch."""
+    time (field 22 of /proc/<pid>/stat; pids are recycled, start times are not) plus the agent's restart count is the
+    same for every rank of the launch and different from every other launch.  ``NPM_LAUNCH_TOKEN`` overrides it for
+    launchers whose ranks are not siblings."""
+    explicit = os.environ.get('NPM_LAUNCH_TOKEN')
+    if explicit:
+        return explicit
     ppid = os.getppid()
     try:
         with open(f'/proc/{ppid}/stat') as f:
             started = f.read().rsplit(')', 1)[1].split()[19]
     except (OSError, IndexError):
         started = '0'
-    return f'{ppid}-{started}'
+    return f'{ppid}-{started}-{os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")}'
+
+
+def _private_dir() -> str:
+    """A directory only this user can write: ``$TMPDIR/npm-<uid>`` with mode 0700, owned by us (anything else at that
+    name -- another user's directory, a symlink -- is refused: a shared /tmp must not let someone else plant an id)."""
+    import stat
+    import tempfile
+    path = os.path.join(tempfile.gettempdir(), f'npm-{os.getuid()}')
+    try:
+        os.mkdir(path, 0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(path)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise _C.NpmError(f'{path} exists and is not a private directory of uid {os.getuid()} (mode 0700): remove it, '
+                          'or name the rendezvous file with NPM_RENDEZVOUS_FILE')
+    return path
 
 
 def rendezvous_path() -> str:
-    """Where rank 0 leaves the 128-byte RCCL id for the other ranks of this node.  ``NPM_RENDEZVOUS_FILE`` (set by
-    the self-launcher) names it outright; under an external launcher it is derived from the launch token, the
-    master port and the restart count, so concurrent or earlier jobs never share a file."""
+    """Where rank 0 leaves the RCCL id for the other ranks of this node.  ``NPM_RENDEZVOUS_FILE`` (set by the
+    self-launcher) names it outright; under an external launcher it lives in a per-user 0700 directory and is derived
+    from the master port and the launch token, so concurrent or earlier jobs never share a file."""
     explicit = os.environ.get('NPM_RENDEZVOUS_FILE')
     if explicit:
         return explicit
-    import tempfile
-    parts = [str(os.getuid()), os.environ.get('MASTER_PORT', '0'), _launch_token(),
-             os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')]
-    return os.path.join(tempfile.gettempdir(), 'npm_rccl_id.' + '.'.join(parts))
+    return os.path.join(_private_dir(), 'rccl_id.' + os.environ.get('MASTER_PORT', '0') + '.' + _launch_token())
+
+
+_ID_MAGIC = b'NPMRCCL1'
+
+
+def _pack_id(uid: bytes) -> bytes:
+    """magic + 2-byte token length + launch token + the 128-byte id.  The token makes a file left behind by another
+    launch (a reused NPM_RENDEZVOUS_FILE, a crashed job) recognisable: readers skip it and keep polling instead of
+    handing a dead bootstrap address to ncclCommInitRank, which would hang."""
+    token = _launch_token().encode()
+    return _ID_MAGIC + len(token).to_bytes(2, 'little') + token + uid
+
+
+def _unpack_id(blob: bytes) -> Optional[bytes]:
+    """The id carried by ``blob`` if it is complete and belongs to THIS launch, else None."""
+    head = len(_ID_MAGIC) + 2
+    if len(blob) < head or not blob.startswith(_ID_MAGIC):
+        return None
+    n = int.from_bytes(blob[len(_ID_MAGIC):head], 'little')
+    if len(blob) != head + n + 128 or blob[head:head + n] != _launch_token().encode():
+        return None
+    return blob[head + n:]
 
 
 def _exchange_unique_id(rank: int, world_size: int, timeout: float = 300.0) -> bytes:
     """Carry rank 0's RCCL id to the other ranks of the node through a file: rank 0 writes it under a temporary
-    name and renames it into place (readers see all 128 bytes or nothing); the others poll.  No third-party
-    runtime is involved -- the product path imports neither torch nor an MPI."""
+    name and renames it into place (readers see all of it or nothing); the others poll, and accept only a file
+    that this user wrote for this launch.  No third-party runtime is involved -- the product path imports neither
+    torch nor an MPI."""
     import time
+    local_world = os.environ.get('LOCAL_WORLD_SIZE')
+    if local_world and int(local_world) != world_size and not os.environ.get('NPM_RENDEZVOUS_FILE'):
+        raise _C.NpmError(f'WORLD_SIZE={world_size} but LOCAL_WORLD_SIZE={local_world}: the RCCL id travels through a '
+                          'file of ONE node (SURVEY.md 8e: the 8 GPUs of a node); for several nodes put '
+                          'NPM_RENDEZVOUS_FILE on a file system all of them share')
     path = rendezvous_path()
     if rank == 0:
         uid = RcclCommunicator.new_unique_id()
         assert len(uid) == 128
         tmp = f'{path}.{os.getpid()}.tmp'
-        with open(tmp, 'wb') as f:
-            f.write(uid)
-        os.replace(tmp, path)
+        fd = os.open(tmp, os.O_WRONLY | os.O_CREAT | os.O_EXCL, 0o600)
+        with os.fdopen(fd, 'wb') as f:
+            f.write(_pack_id(uid))
+        os.replace(tmp, path)                      # also replaces whatever an earlier launch left at this name
         return uid
     deadline = time.monotonic() + timeout
+    seen_foreign = False
     while True:
         try:
             with open(path, 'rb') as f:
-                uid = f.read()
-            if len(uid) == 128:
+                if os.fstat(f.fileno()).st_uid != os.getuid():
+                    raise _C.NpmError(f'rank {rank}: {path} belongs to uid {os.fstat(f.fileno()).st_uid}, not to this '
+                                      'user: refusing an RCCL id somebody else wrote')
+                uid = _unpack_id(f.read())
+            if uid is not None:
                 return uid
+            seen_foreign = True                    # incomplete, or written by another launch: rank 0 will replace it
         except FileNotFoundError:
             pass
         if time.monotonic() > deadline:
-            raise _C.NpmError(f'rank {rank}: no RCCL id from rank 0 at {path} after {timeout:.0f} s')
+            what = 'only a file of another launch' if seen_foreign else 'no file'
+            raise _C.NpmError(f'rank {rank}: no RCCL id from rank 0 at {path} after {timeout:.0f} s ({what}); '
+                              f'launch token {_launch_token()!r}. Ranks must be children of one launcher process on one '
+                              'node (or share NPM_LAUNCH_TOKEN and NPM_RENDEZVOUS_FILE)')
         time.sleep(0.01)
 
 
@@ -183,8 +248,9 @@ def init(reduce: str = 'avg') -> Communicator:
     _C.lib()                                             # bind this process to cuda:LOCAL_RANK first
     uid = _exchange_unique_id(rank, world) if world > 1 else RcclCommunicator.new_unique_id()
     _COMM = RcclCommunicator(rank, world, uid)
-    if world > 1 and rank == 0 and not os.environ.get('NPM_RENDEZVOUS_FILE'):
-        # ncclCommInitRank is collective: every rank has read the id by now (a self-launcher removes its own file)
+    if world > 1 and rank == 0:
+        # ncclCommInitRank is collective: every rank has read the id by now.  Explicit paths are removed too, so a
+        # reused NPM_RENDEZVOUS_FILE never hands a later launch this launch's id.
         try:
             os.unlink(rendezvous_path())
         except OSError:

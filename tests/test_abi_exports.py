@@ -69,7 +69,9 @@ def test_struct_layouts_match_header(built):
     import tempfile
     prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "npm_hip.h"\n#include "npm_comm.h"\n'
             'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(npm_gemm), offsetof(npm_gemm, alpha), '
-            'offsetof(npm_gemm, split_k), sizeof(npm_conv2d), offsetof(npm_conv2d, relu));return 0;}\n')
+            'offsetof(npm_gemm, split_k), sizeof(npm_conv2d), offsetof(npm_conv2d, relu));'
+            'printf("%zu %zu %zu\\n", sizeof(npm_comm_exchange_stats), offsetof(npm_comm_exchange_stats, waits), '
+            'offsetof(npm_comm_exchange_stats, exposed_ms));return 0;}\n')
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, 'abi.c')
         open(src, 'w').write(prog)
@@ -77,7 +79,9 @@ def test_struct_layouts_match_header(built):
         subprocess.run(['gcc', '-std=c99', '-Wall', '-Werror', '-I', os.path.join(ROOT, 'include'), src, '-o', exe], check=True)
         got = [int(v) for v in subprocess.run([exe], check=True, capture_output=True, text=True).stdout.split()]
     want = [ctypes.sizeof(_C.npm_gemm), _C.npm_gemm.alpha.offset, _C.npm_gemm.split_k.offset,
-            ctypes.sizeof(_C.npm_conv2d), _C.npm_conv2d.relu.offset]
+            ctypes.sizeof(_C.npm_conv2d), _C.npm_conv2d.relu.offset,
+            ctypes.sizeof(_C.npm_comm_exchange_stats), _C.npm_comm_exchange_stats.waits.offset,
+            _C.npm_comm_exchange_stats.exposed_ms.offset]
     assert got == want
 
 

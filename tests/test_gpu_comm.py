@@ -102,7 +102,7 @@ def test_self_launched_rank_runs_the_exchange_path():
         env.pop(key, None)
     cmd = [sys.executable, '-m', 'np_modeling_amd.launch', '--gpus', '1', os.path.join(root, 'bench.py'), '--gpus', '1',
            '--steps', '2', '--warmup', '1', '--batch', '4', '--seq', '64', '--features', '128', '--heads', '4',
-           '--hidden', '256', '--no-cpu-baseline', '--no-alt-math']
+           '--hidden', '256', '--no-cpu-baseline', '--no-alt-math', '--no-configs']
     out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = out.stdout.strip().splitlines()
@@ -112,3 +112,44 @@ def test_self_launched_rank_runs_the_exchange_path():
     assert line['exchange']['library'].startswith('/opt/rocm'), line['exchange']
     assert line['exchange']['torch_imported'] is False
     assert 'self-launched' in line['exchange']['launcher']
+
+
+def test_exchange_statistics(comm):
+    """npm_comm_stats: bytes / calls / waits counted, the times non-negative and reset by the read."""
+    from np_modeling_amd import device as D, parallel
+    comm.stats_enable(True)
+    comm.stats()
+    d = D.from_host(np.ones(1 << 18, dtype=np.float32))
+    comm.allreduce_async(d, parallel.AVG)
+    comm.allreduce_async(d.flat_view(0, [1024]), parallel.AVG)
+    comm.wait()
+    got = comm.stats()
+    assert got['bytes'] == 4 * ((1 << 18) + 1024) and got['allreduce_calls'] == 2 and got['waits'] == 1
+    assert got['allreduce_ms'] > 0 and got['exposed_ms'] >= 0
+    again = comm.stats()
+    assert again['bytes'] == 0 and again['allreduce_calls'] == 0 and again['allreduce_ms'] == 0
+    comm.stats_enable(False)
+    comm.allreduce_async(d, parallel.AVG)
+    comm.wait()
+    assert comm.stats()['allreduce_calls'] == 0
+
+
+def test_rank_under_a_per_rank_device_mask():
+    """A launcher that shows each rank ONE GPU (HIP_VISIBLE_DEVICES=<its gpu>) still sets LOCAL_RANK=3: the rank must
+    bind to device 0, the only one it can see -- `bench.py`'s exchange object reports what it bound to."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, NPM_FORCE_RCCL='1', HIP_VISIBLE_DEVICES='0', LOCAL_RANK='3', RANK='0', WORLD_SIZE='1')
+    env.pop('NPM_DEVICE', None)
+    cmd = [sys.executable, os.path.join(root, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1', '--batch', '4',
+           '--seq', '64', '--features', '128', '--heads', '4', '--hidden', '256', '--no-cpu-baseline', '--no-alt-math',
+           '--no-configs']
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = json.loads(out.stdout.strip())
+    assert line['exchange']['device'] == 0 and line['exchange']['visible_devices'] == 1
+    assert line['exchange']['flushes_per_step'] >= 3 and line['exchange']['bytes_per_step'] > 0
+    assert line['exchange']['allreduce_ms'] > 0 and line['exchange']['exposed_ms'] >= 0

@@ -244,14 +244,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_data_parallel_equivalence_gloo():
-    """Two processes, gloo: batch-sharded training of an MLP stack and of pre-/post-norm encoders
+@pytest.mark.parametrize('world', [2, 4])
+def test_data_parallel_equivalence_gloo(world):
+    """Two and four processes, gloo: batch-sharded training of an MLP stack and of pre-/post-norm encoders
     ends with the same parameters as one process on the whole batch."""
     port = _free_port()
     procs = []
-    for rank in range(2):
-        env = dict(os.environ, RANK=str(rank), WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
-                   OMP_NUM_THREADS='2', OPENBLAS_NUM_THREADS='2')
+    for rank in range(world):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port),
+                   OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1')
         procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'dp_worker.py')], env=env,
                                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     outs = []
@@ -473,3 +474,147 @@ def test_dropout_device_rng_plumbing(npm):
     h(x)
     np.random.seed(1)
     np.testing.assert_array_equal(h._mask, np.random.binomial(n=1, p=0.75, size=24).reshape(4, 6))
+
+
+def test_loss_broadcasts_resident_targets(npm, capsys):
+    """Targets of a broadcastable but different shape are valid in the reference (``y - targets``, loss.py:24,28);
+    `Trainer.train` uploads targets once, so the loss has to expand a RESIDENT [B, 1] array too -- the kernels read
+    y.size elements."""
+    D = npm.device
+    y = np.arange(12, dtype=np.float32).reshape(4, 3)
+    t = np.array([[1.0], [2.0], [3.0], [4.0]], dtype=np.float32)
+    for cls, want_l, want_g in ((npm.loss.MSELoss, np.sum((y - t) ** 2) / y.size, 2 * (y - t) / y.size),
+                                (npm.loss.CrossEntropyLoss, -np.sum(t * np.log(y + 1)), -t / (y + 1))):
+        loss = cls()
+        yy = y + 1 if cls is npm.loss.CrossEntropyLoss else y
+        resident = D.from_host(t)
+        assert loss(D.from_host(yy), resident) == pytest.approx(float(want_l), rel=1e-6)
+        np.testing.assert_allclose(np.asarray(loss(backprop=True)), want_g, rtol=1e-6)
+        first = loss._expanded[2]
+        loss(D.from_host(yy), resident)                   # same resident targets: expanded once
+        assert loss._expanded[2] is first
+        with pytest.raises(ValueError):
+            loss(D.from_host(yy), D.from_host(np.zeros([5, 1], dtype=np.float32)))
+    np.random.seed(0)
+    trainer = npm.train.Trainer([npm.layers.Dense(units=3)])
+    trainer.train(rand([4, 5]), t, 2, npm.optimizer.SGDOptimizer(1e-2))       # [4, 1] targets against [4, 3] outputs
+    assert capsys.readouterr().out.count('Loss:') == 2
+
+
+def test_pick_device_policy():
+    """One process per GPU under either kind of launcher: all GPUs visible -> LOCAL_RANK; devices masked per rank
+    (one visible) -> device 0; NPM_DEVICE wins; a mask that is neither is an error, not a silent share."""
+    from np_modeling_amd import _C
+    assert _C.pick_device(8, {'LOCAL_RANK': '5'}) == 5
+    assert _C.pick_device(1, {'LOCAL_RANK': '5'}) == 0          # HIP_VISIBLE_DEVICES=<one GPU> per rank
+    assert _C.pick_device(8, {}) == 0
+    assert _C.pick_device(0, {'LOCAL_RANK': '3'}) == 0          # no device: npm_init reports it
+    assert _C.pick_device(8, {'LOCAL_RANK': '5', 'NPM_DEVICE': '2'}) == 2
+    with pytest.raises(_C.NpmError, match='only 4 HIP devices'):
+        _C.pick_device(4, {'LOCAL_RANK': '5'})
+
+
+def test_current_math_follows_the_library(npm):
+    """A mode set through the tuning knob (NPM_TUNE=10=<mode>, tools/gemm_bench.py --tune) is what current_math()
+    reports: the attention routing (device.mha_core_supported) must not see a stale 'f32'."""
+    from np_modeling_amd import _C
+    assert _C.current_math() == 'f32'
+    _C.lib().npm_set_math(2)
+    try:
+        assert _C.current_math() == 'bf16x3'
+    finally:
+        _C.lib().npm_set_math(0)
+
+
+def test_rendezvous_file_is_private_and_launch_bound(tmp_path, monkeypatch):
+    """The derived rendezvous file lives in a per-user 0700 directory; a file of ANOTHER launch (stale explicit path,
+    planted id) is skipped, a file of another user is refused."""
+    import stat
+    from np_modeling_amd import _C, parallel
+    monkeypatch.setenv('TMPDIR', str(tmp_path))
+    import tempfile
+    monkeypatch.setattr(tempfile, 'tempdir', None)
+    monkeypatch.delenv('NPM_RENDEZVOUS_FILE', raising=False)
+    monkeypatch.setenv('MASTER_PORT', '29123')
+    path = parallel.rendezvous_path()
+    d = os.path.dirname(path)
+    assert os.path.dirname(d) == str(tmp_path) and stat.S_IMODE(os.stat(d).st_mode) == 0o700
+    os.chmod(d, 0o755)
+    with pytest.raises(_C.NpmError, match='not a private directory'):
+        parallel.rendezvous_path()
+    os.chmod(d, 0o700)
+
+    uid = bytes(range(128))
+    monkeypatch.setattr(parallel.RcclCommunicator, 'new_unique_id', staticmethod(lambda: uid))
+    explicit = str(tmp_path / 'explicit_id')
+    monkeypatch.setenv('NPM_RENDEZVOUS_FILE', explicit)
+    monkeypatch.setenv('NPM_LAUNCH_TOKEN', 'old-launch')
+    assert parallel._exchange_unique_id(0, 2) == uid          # an earlier launch leaves its file behind
+    monkeypatch.setenv('NPM_LAUNCH_TOKEN', 'new-launch')
+    with pytest.raises(_C.NpmError, match='only a file of another launch'):
+        parallel._exchange_unique_id(1, 2, timeout=0.2)       # stale id: skipped, not handed to ncclCommInitRank
+    assert parallel._exchange_unique_id(0, 2) == uid          # rank 0 of the new launch replaces it ...
+    assert parallel._exchange_unique_id(1, 2, timeout=5) == uid   # ... and the readers take that one
+    assert stat.S_IMODE(os.stat(explicit).st_mode) == 0o600
+    with open(explicit, 'wb') as f:
+        f.write(uid)                                          # a bare 128-byte id (the old format, or a planted one)
+    with pytest.raises(_C.NpmError, match='another launch'):
+        parallel._exchange_unique_id(1, 2, timeout=0.2)
+
+    monkeypatch.delenv('NPM_RENDEZVOUS_FILE')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '8')
+    with pytest.raises(_C.NpmError, match='ONE node'):
+        parallel._exchange_unique_id(3, 16, timeout=0.2)      # multi-node: fails at once with the reason, not after 300 s
+
+
+def test_self_launcher_eight_ranks(capfd):
+    """The driver's N = 8 shape on CPU ranks: eight fresh children through the launcher's private file."""
+    from np_modeling_amd import launch
+    code = launch.spawn_ranks(8, [sys.executable, os.path.join(ROOT, 'tests', 'uid_worker.py')], build=False,
+                              env=_clean_env())
+    out = capfd.readouterr()
+    assert code == 0, out.err
+    assert 'rank 0/8: id ok' in out.out
+    assert all(f'rank {r}/8: id ok' in out.err for r in range(1, 8)), out.err
+
+
+def test_terminated_launcher_takes_its_ranks_along(tmp_path):
+    """`timeout -k 10 400 python bench.py --gpus N` SIGTERMs the launcher: its ranks (sleeping here) must not
+    survive it, and the launcher's exit code is 143.  A SIGKILLed launcher cannot clean up: the ranks asked the
+    kernel for a SIGTERM on the launcher's death (PR_SET_PDEATHSIG)."""
+    import signal
+    import time
+    pidfile = tmp_path / 'pids'
+
+    def start():
+        if pidfile.exists():
+            pidfile.unlink()
+        env = _clean_env(UID_WORKER_FAIL_RANK='99', UID_WORKER_HANG='1', UID_WORKER_PIDFILE=str(pidfile))
+        p = subprocess.Popen([sys.executable, '-m', 'np_modeling_amd.launch', '--gpus', '3',
+                              os.path.join(ROOT, 'tests', 'uid_worker.py')], env=env, cwd=ROOT,
+                             stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        deadline = time.monotonic() + 120
+        while time.monotonic() < deadline:                    # wait until all three ranks sleep
+            if pidfile.exists() and len(pidfile.read_text().split()) == 3:
+                break
+            time.sleep(0.05)
+        pids = [int(x) for x in pidfile.read_text().split()]
+        assert len(pids) == 3
+        return p, pids
+
+    def gone(pid):
+        try:
+            with open(f'/proc/{pid}/stat') as f:
+                return f.read().rsplit(')', 1)[1].split()[0] == 'Z'
+        except OSError:
+            return True
+
+    for sig, want in ((signal.SIGTERM, 143), (signal.SIGKILL, -9)):
+        p, pids = start()
+        p.send_signal(sig)
+        p.communicate(timeout=60)
+        assert p.returncode == want
+        deadline = time.monotonic() + 20
+        while not all(gone(pid) for pid in pids) and time.monotonic() < deadline:
+            time.sleep(0.05)
+        assert all(gone(pid) for pid in pids), f'ranks survived a launcher ended by signal {sig}: {pids}'

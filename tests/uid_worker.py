@@ -4,7 +4,8 @@ communicator id reaches every other rank through np_modeling_amd/parallel.py:_ex
 product imported no torch on the way.  No GPU, no RCCL: the id is a fixed byte pattern.
 
 ``UID_WORKER_FAIL_RANK=r`` makes rank r exit with code 7 after the exchange (the launcher must stop the others);
-``UID_WORKER_HANG=1`` makes the other ranks wait (they must be terminated, not waited for)."""
+``UID_WORKER_HANG=1`` makes the other ranks wait (they must be terminated, not waited for) after appending their
+pid to ``UID_WORKER_PIDFILE``."""
 
 import os
 import sys
@@ -48,6 +49,9 @@ def main():
         if rank == int(fail_rank):
             sys.exit(7)
         if os.environ.get('UID_WORKER_HANG') == '1':
+            if os.environ.get('UID_WORKER_PIDFILE'):        # the terminated-launcher test watches these processes
+                with open(os.environ['UID_WORKER_PIDFILE'], 'a') as f:
+                    f.write(f'{os.getpid()}\n')
             time.sleep(120)
 
 

@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
 """Throughput of the other BASELINE.json configs on one MI355X (C2 Dense+ReLU, C3 Conv2D, C4 MHA).
 
-    python tools/config_bench.py [--steps 3] [--only C3]
+    python tools/config_bench.py [--steps 3] [--only C3] [--kernels] [--cpu]
 
 Each line: fwd+bwd(+SGD) samples/s, achieved TFLOP/s from the algorithmic FLOPs of SURVEY.md 8d and
-the fraction of the fp32-MFMA peak (157.3 TFLOP/s).  bench.py is the headline (C5)."""
+the fraction of the fp32-MFMA peak (157.3 TFLOP/s).  bench.py is the headline (C5); it imports
+:func:`run_config` / :func:`cpu_baseline` from here for the ``configs`` object of its JSON line, so the numbers
+of this tool and the driver-timed ones come from the same code."""
 
 import argparse
 import os
@@ -12,47 +14,171 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
 PEAK = 157.3
-
-
-KERNELS = False
-
-
 MIN_SECONDS = 0.5
+NAMES = ('C2', 'C3', 'C4')
 
 
-def timed(fn, steps, D):
-    """Seconds per step.  The card needs tens of milliseconds of continuous load to settle at its working clock: a
-    3-step region of C2 (10 ms) read 125 TF where 200 steps read 143 (profiles/r02_config_bench.log), so warm up for
-    MIN_SECONDS / 2 and time at least MIN_SECONDS."""
+def timed(fn, steps, D, min_seconds=None, kernels=False):
+    """(seconds per step, per-kernel summary or None).  The card needs tens of milliseconds of continuous load to
+    settle at its working clock: a 3-step region of C2 (10 ms) read 125 TF where 200 steps read 143
+    (profiles/r02_config_bench.log), so warm up for min_seconds / 2 and time at least min_seconds."""
+    min_seconds = MIN_SECONDS if min_seconds is None else min_seconds
     fn()
     D.synchronize()
     t0 = time.perf_counter()
     fn()
     D.synchronize()
     one = max(time.perf_counter() - t0, 1e-4)
-    for _ in range(int(MIN_SECONDS / 2 / one) + 1):
+    for _ in range(int(min_seconds / 2 / one) + 1):
         fn()
     D.synchronize()
-    steps = max(steps, int(MIN_SECONDS / one) + 1)
+    steps = max(steps, int(min_seconds / one) + 1)
     t0 = time.perf_counter()
     for _ in range(steps):
         fn()
     D.synchronize()
     sec = (time.perf_counter() - t0) / steps
-    if KERNELS:                                   # one more step under the event timer: per-kernel table
+    summary = None
+    if kernels:                                   # one more step under the event timer: per-kernel table
         with D.KernelTimer() as timer:
             fn()
-        rows = sorted(timer.summary().items(), key=lambda kv: -kv[1]['ms'])
-        for name, r in rows:
-            rate = (f"{r['flops'] / r['ms'] / 1e9:7.1f} TFLOP/s" if r['flops'] else
-                    f"{r['bytes'] / r['ms'] / 1e6:7.0f} GB/s   ")
-            print(f"    {name:<22s} x{r['launches']:<3d} {r['ms']:8.3f} ms  {rate}", flush=True)
-    return sec
+        summary = timer.summary()
+    return sec, steps, summary
+
+
+def _fill(D, array, rng, scale=1.0, chunk_rows=8):
+    """Fill a big device tensor from one small host chunk (no multi-GB host array)."""
+    rows = array.shape[0]
+    per = int(np.prod(array.shape[1:]))
+    chunk = rng.standard_normal([chunk_rows] + list(array.shape[1:]), dtype=np.float32) * np.float32(scale)
+    for i in range(0, rows, chunk_rows):
+        n = min(chunk_rows, rows - i)
+        array.flat_view(i * per, [n] + list(array.shape[1:])).set(chunk[:n])
+
+
+def build_config(name, npm, D, rng, conv_batch=256):
+    """(label, batch, algorithmic FLOP per step, step function) of one BASELINE.json config at FULL size."""
+    sgd = npm.optimizer.SGDOptimizer(1e-6)
+    if name == 'C2':
+        b = 4096
+        layer = npm.layers.Dense(units=4096)
+        x = D.from_host(rng.standard_normal([b, 4096], dtype=np.float32))
+        dy = D.from_host(rng.standard_normal([b, 4096], dtype=np.float32))
+        layer(x)
+        layer.linear._w = (np.asarray(layer.linear.w) / 64).astype(np.float32)
+        label, flops = 'Dense(4096->4096)+ReLU fwd+bwd+SGD, batch 4096 (BASELINE.json configs[1])', 3 * 2.0 * b * 4096 * 4096
+    elif name == 'C3':
+        b = conv_batch
+        layer = npm.layers.Conv2D(channels=128, kernel_size=3)
+        x = D.empty([b, 224, 224, 64])
+        _fill(D, x, rng)
+        dy = D.empty([b, 224, 224, 128])
+        _fill(D, dy, rng, 0.01)
+        layer(x)
+        layer._w = (np.asarray(layer.w) / 24).astype(np.float32)
+        label = f'Conv2D(64->128, k=3, SAME)+ReLU on 224x224 NHWC fwd+bwd+SGD, batch {b} (BASELINE.json configs[2])'
+        flops = 3 * 2.0 * b * 224 * 224 * 128 * 576
+    elif name == 'C4':
+        b, s, f, h = 256, 512, 1024, 8
+        layer = npm.layers.MultiHeadAttention(num_heads=h)
+        x = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32))
+        dy = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01))
+        layer(x)
+        for n in ('_wq', '_wk', '_wv', '_wo'):
+            setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
+        label = 'MultiHeadAttention d_model=1024 heads=8 seq=512 fwd+bwd+SGD, batch 256 (BASELINE.json configs[3])'
+        flops = 12 * 2.0 * b * s * f * f + 6 * 2.0 * b * s * s * f
+    else:
+        raise ValueError(name)
+
+    def step():
+        layer(x)
+        layer(dy, backprop=True, optimizer_=sgd)
+    return label, b, flops, step
+
+
+def run_config(name, npm, D, steps=3, min_seconds=None, kernels=True, conv_batch=256):
+    """One config -> the dict bench.py puts under ``configs[name]``."""
+    label, batch, flops, step = build_config(name, npm, D, np.random.default_rng(0), conv_batch)
+    sec, steps, summary = timed(step, steps, D, min_seconds, kernels)
+    out = {'workload': label, 'value': batch / sec, 'unit': 'samples/s', 'ms_per_step': 1e3 * sec, 'steps': steps,
+           'tflops': flops / sec / 1e12, 'frac_of_fp32_mfma_peak': flops / sec / 1e12 / PEAK, 'math': npm._C.current_math()}
+    if summary:
+        rows = sorted(summary.items(), key=lambda kv: -kv[1]['ms'])
+        out['kernels'] = {k: ({'launches': r['launches'], 'ms': r['ms'], 'tflops': r['flops'] / r['ms'] / 1e9} if r['flops'] else
+                              {'launches': r['launches'], 'ms': r['ms'], 'GBps': r['bytes'] / r['ms'] / 1e6}) for k, r in rows}
+        top, r = rows[0]
+        out['dominant_kernel'] = {'name': top, 'share_of_step_time': r['ms'] / (1e3 * sec),
+                                  'tflops': r['flops'] / r['ms'] / 1e9 if r['flops'] else None,
+                                  'frac': r['flops'] / r['ms'] / 1e9 / PEAK if r['flops'] else None}
+    return out
+
+
+def cpu_baseline(name, budget_s=10.0):
+    """The NumPy oracle (checker; closed-form flavour, BLAS GEMMs) timed on the host cores on a bounded sample of the
+    config, per BASELINE.md section 3: C2 at the full shape, C3 at batch <= 8 (the reference's fp64 arithmetic, as
+    conv.py computes), C4 at batch 2."""
+    from oracle import np_oracle as O
+    rng = np.random.default_rng(1)
+    if name == 'C2':
+        b = 4096
+        x = rng.standard_normal([b, 4096], dtype=np.float32)
+        dy = rng.standard_normal([b, 4096], dtype=np.float32)
+        w = rng.standard_normal([4096, 4096], dtype=np.float32) / np.float32(64)
+        bias = np.zeros([4096], dtype=np.float32)
+
+        def step():
+            y, pre = O.dense_fwd(x, w, bias)
+            dx, dw, db = O.dense_bwd(x, w, pre, dy)
+            O.sgd_step(w, dw, 1e-6)
+            O.sgd_step(bias, db, 1e-6)
+        sample = f'Dense(4096->4096)+ReLU fwd+bwd+SGD at the full shape, batch {b}, fp32 sgemm (mlp.py:21-40,70-77)'
+    elif name == 'C3':
+        b = 4
+        x = rng.standard_normal([b, 224, 224, 64], dtype=np.float32)
+        dy = rng.standard_normal([b, 224, 224, 128], dtype=np.float32)
+        w = rng.standard_normal([3, 3, 64, 128], dtype=np.float32) / np.float32(24)
+        bias = np.zeros([128], dtype=np.float32)
+
+        def step():
+            y, pre = O.conv_layer_fwd(x, w, bias)
+            dx, dw, db = O.conv_layer_bwd(x, w, pre, dy)
+            O.sgd_step(w, dw, 1e-6)
+            O.sgd_step(bias, db, 1e-6)
+        sample = (f'Conv2D(64->128,k=3) 224x224 fwd+bwd+SGD, batch {b} of 256 (the reference pads into fp64, conv.py:97: k*k '
+                  'shifted dgemms; its temporaries are 40 GB at the full batch)')
+    elif name == 'C4':
+        b, s, f, h = 2, 512, 1024, 8
+        p = {k: (rng.standard_normal(shape, dtype=np.float32) / np.float32(32 if k.startswith('w') else 1))
+             for k, shape in dict(wq=[h, f // h, f], wk=[h, f // h, f], wv=[h, f // h, f], wo=[f, h, f // h],
+                                  bq=[h, f // h], bk=[h, f // h], bv=[h, f // h], bo=[f]).items()}
+        q = rng.standard_normal([b, s, f], dtype=np.float32)
+        dy = rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01)
+
+        def step():
+            _, cache = O.mha_fwd(p, q)
+            _, grads = O.mha_bwd(p, cache, dy)
+            for k in p:
+                O.sgd_step(p[k], grads[k], 1e-6)
+        sample = (f'MultiHeadAttention d=1024 h=8 seq=512 fwd+bwd+SGD, batch {b} of 256, closed-form softmax gradient and BLAS '
+                  'contractions (the reference\'s own einsum + Jacobian form takes 174 s at this batch, BASELINE.md section 2)')
+    else:
+        raise ValueError(name)
+    times = []
+    t_all = time.perf_counter()
+    while len(times) < 3 and (not times or time.perf_counter() - t_all + times[-1] < budget_s):
+        t0 = time.perf_counter()
+        step()
+        times.append(time.perf_counter() - t0)
+    best = min(times)
+    return {'value': b / best, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
+            'sample': f'NumPy oracle: {sample}; best of {len(times)} steps ({best:.2f} s/step)'}
 
 
 def main():
@@ -62,66 +188,24 @@ def main():
     ap.add_argument('--only', default='')
     ap.add_argument('--conv-batch', type=int, default=256)
     ap.add_argument('--kernels', action='store_true', help='per-kernel HIP-event table after each line')
+    ap.add_argument('--cpu', action='store_true', help='also time the NumPy oracle on the host cores (bounded samples)')
     args = ap.parse_args()
-    global KERNELS, MIN_SECONDS
-    KERNELS = args.kernels
-    MIN_SECONDS = args.min_seconds
     import np_modeling_amd as npm
     from np_modeling_amd import device as D
-    rng = np.random.default_rng(0)
-    sgd = npm.optimizer.SGDOptimizer(1e-6)
 
-    def report(name, batch, flops, sec):
-        print(f'{name}: {batch / sec:10.1f} samples/s  {sec * 1e3:8.2f} ms/step  {flops / sec / 1e12:6.1f} TFLOP/s '
-              f'({100 * flops / sec / 1e12 / PEAK:4.1f} % of fp32-MFMA peak)', flush=True)
-
-    if not args.only or args.only == 'C2':
-        b = 4096
-        layer = npm.layers.Dense(units=4096)
-        x = D.from_host(rng.standard_normal([b, 4096], dtype=np.float32))
-        dy = D.from_host(rng.standard_normal([b, 4096], dtype=np.float32))
-        layer(x)
-        layer.linear._w = (np.asarray(layer.linear.w) / 64).astype(np.float32)
-
-        def step():
-            layer(x)
-            layer(dy, backprop=True, optimizer_=sgd)
-        report('C2 Dense(4096->4096)+ReLU b=4096', b, 3 * 2.0 * b * 4096 * 4096, timed(step, args.steps, D))
-
-    if not args.only or args.only == 'C3':
-        b = args.conv_batch
-        layer = npm.layers.Conv2D(channels=128, kernel_size=3)
-        x = D.empty([b, 224, 224, 64])
-        chunk = rng.standard_normal([8, 224, 224, 64], dtype=np.float32)
-        for i in range(0, b, 8):                   # fill the 3.3 GB input without a 3.3 GB host array
-            x.flat_view(i * 224 * 224 * 64, [min(8, b - i), 224, 224, 64]).set(chunk[:min(8, b - i)])
-        dy = D.empty([b, 224, 224, 128])
-        chunk = rng.standard_normal([8, 224, 224, 128], dtype=np.float32) * np.float32(0.01)
-        for i in range(0, b, 8):
-            dy.flat_view(i * 224 * 224 * 128, [min(8, b - i), 224, 224, 128]).set(chunk[:min(8, b - i)])
-        layer(x)
-        layer._w = (np.asarray(layer.w) / 24).astype(np.float32)
-
-        def step():
-            layer(x)
-            layer(dy, backprop=True, optimizer_=sgd)
-        flops = 3 * 2.0 * b * 224 * 224 * 128 * 576
-        report(f'C3 Conv2D(64->128,k=3) 224x224 b={b}', b, flops, timed(step, args.steps, D))
-
-    if not args.only or args.only == 'C4':
-        b, s, f, h = 256, 512, 1024, 8
-        layer = npm.layers.MultiHeadAttention(num_heads=h)
-        q = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32))
-        dy = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01))
-        layer(q)
-        for n in ('_wq', '_wk', '_wv', '_wo'):
-            setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
-
-        def step():
-            layer(q)
-            layer(dy, backprop=True, optimizer_=sgd)
-        flops = 12 * 2.0 * b * s * f * f + 6 * 2.0 * b * s * s * f
-        report('C4 MultiHeadAttention d=1024 h=8 seq=512 b=256', b, flops, timed(step, args.steps, D))
+    for name in NAMES:
+        if args.only and args.only != name:
+            continue
+        r = run_config(name, npm, D, args.steps, args.min_seconds, args.kernels, args.conv_batch)
+        for k, row in (r.get('kernels') or {}).items():
+            rate = f"{row['tflops']:7.1f} TFLOP/s" if 'tflops' in row else f"{row['GBps']:7.0f} GB/s   "
+            print(f"    {k:<22s} x{row['launches']:<3d} {row['ms']:8.3f} ms  {rate}", flush=True)
+        print(f"{name} {r['workload']}: {r['value']:10.1f} samples/s  {r['ms_per_step']:8.2f} ms/step  {r['tflops']:6.1f} TFLOP/s "
+              f"({100 * r['frac_of_fp32_mfma_peak']:4.1f} % of fp32-MFMA peak)", flush=True)
+        D.trim_pool()
+        if args.cpu:
+            c = cpu_baseline(name)
+            print(f"    cpu_baseline: {c['value']:.3f} samples/s on {c['cores']} cores -- {c['sample']}", flush=True)
 
 
 if __name__ == '__main__':
