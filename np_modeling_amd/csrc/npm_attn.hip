@@ -130,6 +130,65 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void *base, lo
     return __builtin_amdgcn_make_buffer_rsrc((void *)base, 0, (int)std::min<long>(std::max<long>(bytes, 0), 0x7FFFFFF0L), 0x00020000);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA issued from inline assembly.  Through the builtin, hipcc (ROCm 7.2) knows that an LDS-DMA piece is a
+// pending LDS write on the vector-memory counter and puts `s_waitcnt vmcnt(0)` in front of the next ds_read in the same
+// basic block -- i.e. right after the NEXT tile's pieces were issued it waits for them, and every other outstanding
+// load, before reading the CURRENT tile: the prefetch never overlapped anything (both kernels of round 2 had that wait;
+// whether it appears depends on the control flow between issue and read).  These pipelines order their stages
+// themselves (a counted `s_waitcnt vmcnt` + the workgroup barrier at the top of every tile), so the pieces are
+// invisible to the compiler: no wait of its own, no VALU for the addresses (the tile offset is the SCALAR offset of
+// the instruction, range-checked together with the lane's offset), M0 saved and restored around each group.
+// hipcc's counted waits for its OWN loads do not see these pieces; a piece issued after such a load only makes that
+// wait stricter than needed (loads return in order), never too lax.
+// ---------------------------------------------------------------------------------------------------------------
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4_t make_desc(const void *base, long bytes) {      // the words of make_rsrc, in SGPRs
+    const unsigned long a = (unsigned long)base;
+    i32x4_t d;
+    d.x = __builtin_amdgcn_readfirstlane((int)a);
+    d.y = __builtin_amdgcn_readfirstlane((int)(a >> 32) & 0xffff);
+    d.z = __builtin_amdgcn_readfirstlane((int)std::min<long>(std::max<long>(bytes, 0), 0x7FFFFFF0L));
+    d.w = 0x00020000;
+    return d;
+}
+__device__ __forceinline__ unsigned lds_offset(const float *p) {                  // byte address inside LDS (wave-uniform)
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(npm_tile::lds_void *)p);
+}
+
+// N consecutive 1 KiB pieces starting at LDS byte address `lds`: piece i copies 16 bytes per lane from
+// (desc, voff[i] + soff).  The wait state between a write of M0 and the instruction that reads it is the s_nop.
+#define NPM_DMA_FIRST "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+#define NPM_DMA_NEXT "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define NPM_DMA_LOAD(v) "buffer_load_dwordx4 " v ", %2, %3 offen lds\n\t"
+#define NPM_DMA_LAST "s_mov_b32 m0, %0"
+__device__ __forceinline__ void dma_group1(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_group2(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0, unsigned v1) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_NEXT NPM_DMA_LOAD("%5") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0), "v"(v1) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_group4(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_NEXT NPM_DMA_LOAD("%5") NPM_DMA_NEXT NPM_DMA_LOAD("%6") NPM_DMA_NEXT NPM_DMA_LOAD("%7") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory", "scc");
+}
+template <int N>
+__device__ __forceinline__ void dma_group(i32x4_t desc, unsigned lds, unsigned soff, const unsigned (&v)[N]) {
+    static_assert(N == 1 || N == 2 || N % 4 == 0, "pieces per wave");
+    if constexpr (N == 1) dma_group1(desc, lds, soff, v[0]);
+    else if constexpr (N == 2) dma_group2(desc, lds, soff, v[0], v[1]);
+    else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) dma_group4(desc, lds + i * 1024, soff, v[i], v[i + 1], v[i + 2], v[i + 3]);
+    }
+}
+
 #define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
 
 // Instruction-order hints for one phase of `steps` steps, each `reads` LDS reads feeding `mfmas` MFMAs: the reads
@@ -167,7 +226,7 @@ __device__ __forceinline__ void zero16(f32x16 &x) {
 // its Q fragment (D / 2 registers) and O^T accumulators (D / 2 registers) resident.  K and V tiles of 32 keys
 // stream through two LDS stages; one barrier per tile; two blocks per CU.
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, bool MASK, bool SAVE>
+template <int D, bool MASK, bool SAVE, bool TRACE>
 __global__ void __launch_bounds__(256, 2)
 mha_fwd_kernel(const MhaArgs p) {
     using T = Tile<D>;
@@ -176,7 +235,7 @@ mha_fwd_kernel(const MhaArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    long long *const blk_tr = (p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;   // block-level stamps 9..13
+    long long *const blk_tr = (TRACE && p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;   // block-level stamps 9..13
     if (blk_tr) blk_tr[9] = __builtin_amdgcn_s_memtime();
     const int l32 = lane & 31, half = lane >> 5;
 
@@ -186,8 +245,8 @@ mha_fwd_kernel(const MhaArgs p) {
     const int qrow = qt * 128 + wave * 32 + l32;                             // this lane's query
     const bool qok = qrow < p.seq_q;
 
-    const auto rsrcK = make_rsrc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
-    const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
+    const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto descV = make_desc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
     const auto rsrcQ = make_rsrc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
 
     // Q fragment: element s of group g is Q[qrow][8 g + 4 half + s]
@@ -202,14 +261,11 @@ mha_fwd_kernel(const MhaArgs p) {
         vv[i] = T::src(lane, wave * PPW + i, p.v_pitch);
     }
     const unsigned kstep = (unsigned)(32 * p.k_pitch * 4), vstep = (unsigned)(32 * p.v_pitch * 4);
+    const unsigned lds_k = lds_offset(smem + wave * PPW * 256), lds_v = lds_k + 2 * TILE * 4;      // this wave's pieces, stage 0
     auto issue = [&](int t, int stage) {
-#pragma unroll
-        for (int i = 0; i < PPW; ++i) {
-            const int j = wave * PPW + i;
-            if (j < PIECES) {                                                 // the row offset rides the VGPR offset: it is range-checked
-                lds_dma16(rsrcK, smem + stage * TILE + j * 256, vk[i] + t * kstep, 0);
-                lds_dma16(rsrcV, smem + (2 + stage) * TILE + j * 256, vv[i] + t * vstep, 0);
-            }
+        if (PIECES % 4 == 0 || wave * PPW < PIECES) {     // D = 16: two pieces per tile, waves 0 and 1 (PPW = 1)
+            dma_group<PPW>(descK, lds_k + stage * TILE * 4, t * kstep, vk);   // the tile's first row = the scalar offset: range-checked
+            dma_group<PPW>(descV, lds_v + stage * TILE * 4, t * vstep, vv);
         }
     };
 
@@ -224,7 +280,12 @@ mha_fwd_kernel(const MhaArgs p) {
     const float c = p.scale * LOG2E;
     const int nt = (p.seq_kv + 31) / 32;
     const unsigned char *mrow = MASK ? p.mask + b * p.mask_sb + h * p.mask_sh + (long)qrow * p.mask_sq : nullptr;
-    float *srow = SAVE ? p.scores + ((long)bh * p.seq_q + qrow) * p.seq_kv : nullptr;
+    // Saved scores of this (b, h): [seq_q][seq_kv] behind one descriptor.  A lane's part of the address (its query row,
+    // its 4 half keys) is ONE register, the tile's first key a scalar offset, the register group an immediate: a full
+    // tile is four bare buffer_store_dwordx4, rows beyond seq_q carry an out-of-range offset.
+    const auto rsrcS = make_rsrc(SAVE ? p.scores + (long)bh * p.seq_q * p.seq_kv : nullptr, SAVE ? (long)p.seq_q * p.seq_kv * 4 : 0);
+    const int svoff = qok ? (int)(((long)qrow * p.seq_kv + 4 * half) * 4) : OOB;
+    const bool rows16 = (p.seq_kv & 3) == 0;             // every score row starts 16-byte aligned
 
     issue(0, 0);
     // The two blocks of a CU run the same program; started together they reach their softmax (no MFMA) together and
@@ -236,8 +297,8 @@ mha_fwd_kernel(const MhaArgs p) {
     if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int t = 0; t < nt; ++t) {
         npm_tile::dma_barrier();                        // tile t has landed (every wave's pieces); nobody still reads the stage refilled next
-        long long *tr = (p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
-        if (p.trace && tid == 0 && t == (nt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime(); FENCE(); }
+        long long *tr = (TRACE && p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
+        if (TRACE && p.trace && tid == 0 && t == (nt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime(); FENCE(); }
         STAMP(0);
         if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
         const float *sK = smem + (t & 1) * TILE, *sV = smem + (2 + (t & 1)) * TILE;
@@ -273,14 +334,20 @@ mha_fwd_kernel(const MhaArgs p) {
                 if (kv < p.seq_kv && mrow[kv] == 0) S[r] = -INFINITY;
             }
         }
-        if (SAVE && qok) {
+        if (SAVE) {
+            const int stile = 32 * t * 4;                                     // scalar: byte offset of the tile's first key
+            if (rows16 && 32 * t + 32 <= p.seq_kv) {
 #pragma unroll
-            for (int g4 = 0; g4 < 4; ++g4) {
-                const int kv = kv0 + 8 * g4;
-                if (kv + 3 < p.seq_kv) *reinterpret_cast<float4 *>(srow + kv) = make_float4(S[4 * g4], S[4 * g4 + 1], S[4 * g4 + 2], S[4 * g4 + 3]);
-                else
-                    for (int e = 0; e < 4; ++e)
-                        if (kv + e < p.seq_kv) srow[kv + e] = S[4 * g4 + e];
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    const u32x4_t v = {__float_as_uint(S[4 * g4]), __float_as_uint(S[4 * g4 + 1]), __float_as_uint(S[4 * g4 + 2]), __float_as_uint(S[4 * g4 + 3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrcS, svoff + 32 * g4, stile, 0);
+                }
+            } else {                                                          // ragged last tile / unaligned rows: element by element
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int e = (r & 3) + 8 * (r >> 2);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[r]), rsrcS, (qok && kv0 + e < p.seq_kv) ? svoff + 4 * e : OOB, stile, 0);
+                }
             }
         }
         // ---- online softmax in the exp2 domain: the statistics of query `qrow` live on its two lanes.  The running
@@ -295,17 +362,23 @@ mha_fwd_kernel(const MhaArgs p) {
         float m_new = m;
         if (__builtin_amdgcn_ballot_w64(tmax > m + RESCALE) != 0) {       // first tile: m = -inf
             m_new = fmaxf(m, tmax);
-            const float alpha = fast_exp2(m - m_new);
+            // A row whose keys were ALL masked so far (m = -inf: l = 0, O = 0) keeps alpha finite: exp2(-inf - (-inf)) is
+            // NaN and would poison a row that still has keys to come (banded, left-padded, block-diagonal masks)
+            const float alpha = (MASK && m == -INFINITY) ? 0.f : fast_exp2(m - m_new);
             l *= alpha;
 #pragma unroll
             for (int t2 = 0; t2 < DT; ++t2)
 #pragma unroll
                 for (int e = 0; e < 16; ++e) O[t2][e] *= alpha;
         }
+        // ... and takes its exponents against 0 while its reference point is still -inf: masked entries give
+        // exp2(-inf) = 0, not fma(-inf, c, +inf) = NaN.  Only a row with NO key left ends with l = 0 -> NaN, as
+        // np.where(mask, s, -inf) followed by the softmax does (attentions.py:105-109).
+        const float m_use = (MASK && m_new == -INFINITY) ? 0.f : m_new;
         float psum = 0.f;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            S[r] = fast_exp2(fmaf(S[r], c, -m_new));
+            S[r] = fast_exp2(fmaf(S[r], c, -m_use));
             psum += S[r];
         }
         l += psum + xhalf(psum);
@@ -357,22 +430,23 @@ mha_fwd_kernel(const MhaArgs p) {
 // The row terms LSE (from the forward) and delta = rowsum(dO * O) (mha_delta_kernel, 8 B/element of [B,S,H,D]) are
 // read one tile ahead, one value per lane, and turned from "query on the lane" into "query in the registers" through LDS.
 // ---------------------------------------------------------------------------------------------------------------
-template <int D, bool MASK, bool SAVED>
+template <int D, bool MASK, bool SAVED, bool TRACE>
 __global__ void __launch_bounds__(256, 1)
 mha_bwd_kernel(const MhaArgs p) {
     using T = Tile<D>;
     using TS = Tile<128>;
     constexpr int NG = D / 8, DT = (D + 31) / 32, VEC = T::VEC, QTILE = 32 * D, KBLK = 128 * D;
     constexpr int QPIECES = D / 8, QPPW = (QPIECES + 3) / 4, KPPW = D / 8;       // K block: D / 2 pieces, D / 8 per wave
-    __shared__ __attribute__((aligned(16))) float sKB[KBLK];
-    __shared__ __attribute__((aligned(16))) float sQ[2 * QTILE];
-    __shared__ __attribute__((aligned(16))) float sDO[2 * QTILE];
-    __shared__ __attribute__((aligned(16))) float sDS[32 * 128];
-    __shared__ float sRow[4 * 64];
+    // ONE __shared__ object: with several, hipcc's wait-count pass learns which of them an LDS-DMA piece writes and
+    // puts `s_waitcnt vmcnt(0)` in front of the next ds_read of that object -- here the read of the CURRENT Q / dO stage
+    // right after the NEXT stage's pieces were issued: the whole prefetch drained once per tile.  The pipeline's
+    // waits are explicit (counted vmcnt + barrier at the top of the tile).
+    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + 32 * 128 + 4 * 64];
+    float *const sKB = smem, *const sQ = sKB + KBLK, *const sDO = sQ + 2 * QTILE, *const sDS = sDO + 2 * QTILE, *const sRow = sDS + 32 * 128;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    long long *const blk_tr = (p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;   // block-level stamps 9..13
+    long long *const blk_tr = (TRACE && p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;   // block-level stamps 9..13
     if (blk_tr) blk_tr[9] = __builtin_amdgcn_s_memtime();
     const int l32 = lane & 31, half = lane >> 5;
     const int dcol = D < 32 ? (l32 & (D - 1)) : l32;
@@ -380,16 +454,22 @@ mha_bwd_kernel(const MhaArgs p) {
     const int b = bh / p.heads, h = bh - b * p.heads;
     float *xs = sRow + wave * 64;
 
-    const auto rsrcK = make_rsrc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
     const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
-    const auto rsrcQ = make_rsrc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
-    const auto rsrcDO = make_rsrc(p.dctx + (long)b * p.seq_q * p.dctx_pitch + h * D, ((long)(p.seq_q - 1) * p.dctx_pitch + D) * 4);
+    const auto descQ = make_desc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
+    const auto descDO = make_desc(p.dctx + (long)b * p.seq_q * p.dctx_pitch + h * D, ((long)(p.seq_q - 1) * p.dctx_pitch + D) * 4);
     const auto rsrcDQ = make_rsrc(p.dq + (long)b * p.seq_q * p.dq_pitch + h * D, ((long)(p.seq_q - 1) * p.dq_pitch + D) * 4);
     const auto rsrcDK = make_rsrc(p.dk + (long)b * p.seq_kv * p.dk_pitch + h * D, ((long)(p.seq_kv - 1) * p.dk_pitch + D) * 4);
     const auto rsrcDV = make_rsrc(p.dv + (long)b * p.seq_kv * p.dv_pitch + h * D, ((long)(p.seq_kv - 1) * p.dv_pitch + D) * 4);
     // an empty descriptor: every access through it is out of range (loads give 0, stores are dropped)
     const auto rsrcNone = make_rsrc(p.dq, 0);
-    const float *lse = p.lse + (long)bh * p.seq_q, *dlt = p.delta + (long)bh * p.seq_q;
+    // Row terms and saved scores of this (b, h) behind descriptors: a row beyond seq_q (a tile past the end, the
+    // prefetch of the last tile) is out of range and reads 0 -- no branch, no exec masking around any of these loads.
+    const auto rsrcL = make_rsrc(p.lse + (long)bh * p.seq_q, (long)p.seq_q * 4);
+    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.seq_q, (long)p.seq_q * 4);
+    const auto rsrcS = make_rsrc(SAVED ? p.scores + (long)bh * p.seq_q * p.seq_kv : nullptr, SAVED ? (long)p.seq_q * p.seq_kv * 4 : 0);
+    const int srow_bytes = p.seq_kv * 4;
+    const auto rsrcM = make_rsrc(MASK ? p.mask + b * p.mask_sb + h * p.mask_sh : nullptr, MASK ? (long)(p.seq_q - 1) * p.mask_sq + p.seq_kv : 0);
 
     unsigned vq[QPPW], vdo[QPPW], vkb[KPPW];
 #pragma unroll
@@ -400,16 +480,15 @@ mha_bwd_kernel(const MhaArgs p) {
 #pragma unroll
     for (int i = 0; i < KPPW; ++i) vkb[i] = T::src(lane, wave * KPPW + i, p.k_pitch);
     const unsigned qstep = (unsigned)(32 * p.q_pitch * 4), dostep = (unsigned)(32 * p.dctx_pitch * 4);
-    // DMA piece i (0 .. 2 QPPW - 1) of this wave for tile qt: the Q pieces first, then the dO pieces.  A tile beyond
-    // the last one reads out of range (zeros into a stage nobody reads): no branch around the issue.
-    auto issue_piece = [&](int qt, int stage, int i) {
-        const int j = wave * QPPW + (i % QPPW);
-        if (j < QPIECES) {
-            if (i < QPPW) lds_dma16(rsrcQ, sQ + stage * QTILE + j * 256, vq[i % QPPW] + qt * qstep, 0);
-            else lds_dma16(rsrcDO, sDO + stage * QTILE + j * 256, vdo[i % QPPW] + qt * dostep, 0);
+    // The Q pieces (which = 0) or the dO pieces (which = 1) of this wave for tile qt; the tile's first row is the
+    // scalar offset of the group.
+    const unsigned lds_q = lds_offset(sQ + wave * QPPW * 256), lds_do = lds_offset(sDO + wave * QPPW * 256);
+    auto issue_half = [&](int qt, int stage, int which) {
+        if (QPIECES % 4 == 0 || wave * QPPW < QPIECES) {     // D = 16: two pieces per tile, waves 0 and 1
+            if (which == 0) dma_group<QPPW>(descQ, lds_q + stage * QTILE * 4, qt * qstep, vq);
+            else dma_group<QPPW>(descDO, lds_do + stage * QTILE * 4, qt * dostep, vdo);
         }
     };
-    constexpr int NP = 2 * QPPW;               // DMA pieces per wave and tile
 
     const float c = p.scale * LOG2E;
     const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
@@ -445,11 +524,8 @@ mha_bwd_kernel(const MhaArgs p) {
     // the LAST query tile of the current one (behind a barrier that says every wave is done with the K block, in
     // front of that tile's 64 dK MFMAs), its first Q / dO tile -- tile 0 again -- is the regular "next tile" prefetch
     // of that last tile, and this block's dK / dV stores stay in flight behind a counted wait.
-    auto issue_kblock = [&](int kb) {
-        const unsigned kboff = (unsigned)(kb * 128 * p.k_pitch * 4);
-#pragma unroll
-        for (int i = 0; i < KPPW; ++i) lds_dma16(rsrcK, sKB + (wave * KPPW + i) * 256, vkb[i] + kboff, 0);
-    };
+    const unsigned lds_kb = lds_offset(sKB + wave * KPPW * 256);
+    auto issue_kblock = [&](int kb) { dma_group<KPPW>(descK, lds_kb, (unsigned)(kb * 128 * p.k_pitch * 4), vkb); };
     float4 vf[NG];                                                               // V[key][8 g + 4 half + s] of the current block
     auto load_vfrag = [&](int kb) {
         const int row = kb * 128 + kvl;
@@ -459,11 +535,12 @@ mha_bwd_kernel(const MhaArgs p) {
     constexpr int SEAM_STORES = VEC == 4 ? 32 + 4 : 0;   // D = 128: 32 dK/dV stores + the last tile's 4 dQ stores stay in flight
     issue_kblock(0);
     load_vfrag(0);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) issue_piece(0, 0, i);
+    issue_half(0, 0, 0);
+    issue_half(0, 0, 1);
     int it = 0;                                          // tiles done so far: stage parity
     // Row terms of the next tile (one query per lane), fetched one tile ahead -- across the seams too
-    float lse_n = l32 < p.seq_q ? lse[l32] * LOG2E : 0.f, dlt_n = l32 < p.seq_q ? dlt[l32] : 0.f;
+    float lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, l32 * 4, 0, 0));
+    float dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, l32 * 4, 0, 0));
 
     if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int kb = 0; kb < nkb; ++kb) {
@@ -487,41 +564,49 @@ mha_bwd_kernel(const MhaArgs p) {
             asm volatile("" ::: "memory");
             const bool seam = qt + 1 == nqt && kb + 1 < nkb;      // last tile of a key block that has a successor
             const int nq = qt + 1 < nqt ? qt + 1 : 0;             // the next tile to prefetch: wraps to the next block's tile 0
-            long long *tr = (p.trace && tid == 0 && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
-            if (p.trace && tid == 0 && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime(); FENCE(); }
+            long long *tr = (TRACE && p.trace && tid == 0 && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
+            if (TRACE && p.trace && tid == 0 && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 8] = __builtin_amdgcn_s_memtime(); FENCE(); }
             STAMP(0);
             const int cur = it & 1, nxt = cur ^ 1;
             const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
             const int q0 = 32 * qt;
             // Row terms, from "query on the lane" to "query in the registers", through 256 bytes of LDS private to the
             // wave; read back at once (a read inside a later phase would wait behind that phase's operand prefetch).
-            if (half == 0) { xs[l32] = lse_n; xs[32 + l32] = dlt_n; }
+            if (half == 0) { xs[l32] = lse_n * LOG2E; xs[32 + l32] = dlt_n; }    // (the multiply HERE: at the load it would wait for it)
             float Lr[16], Dr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 Lr[r] = xs[4 * half + (r & 3) + 8 * (r >> 2)];
                 Dr[r] = xs[32 + 4 * half + (r & 3) + 8 * (r >> 2)];
             }
-            {
-                const int nrow = 32 * nq + l32;
-                const bool nok = nrow < p.seq_q;
-                lse_n = nok ? lse[nrow] * LOG2E : 0.f;
-                dlt_n = nok ? dlt[nrow] : 0.f;
-            }
+            lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, l32 * 4, 32 * nq * 4, 0));
+            dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, l32 * 4, 32 * nq * 4, 0));
             const int dq_tile = q0 * (int)p.dq_pitch * 4;                         // scalar: byte offset of the tile's first row
-            float4 dq_old[4];
+            // Old dQ^T values of this wave's slice (head dimensions 8 g + 4 half .. of query q0 + l32; zeros in the first key
+            // block): requested now, they become the INITIAL VALUE of the dQ accumulator -- the sum over the key blocks
+            // costs no add, and the last of this tile's compiler-visible loads is consumed before the next tile's
+            // LDS-DMA pieces go out (a later use would make hipcc's counted wait drain those too).
+            f32x16 acc;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                if (8 * g < D) {
+                    const u32x4_t o = __builtin_amdgcn_raw_buffer_load_b128(rsrcOld, dq_voff + 32 * g, dq_tile, 0);
+                    acc[4 * g] = __uint_as_float(o.x); acc[4 * g + 1] = __uint_as_float(o.y);
+                    acc[4 * g + 2] = __uint_as_float(o.z); acc[4 * g + 3] = __uint_as_float(o.w);
+                } else {
+                    acc[4 * g] = acc[4 * g + 1] = acc[4 * g + 2] = acc[4 * g + 3] = 0.f;
+                }
+            }
             f32x16 S, P, dP, dS;
             float4 fa[2], fk[2];                       // row fragments, one step ahead
             float ea[2][4];                            // column vectors, one step ahead
             if (SAVED) {
-                const float *sc = p.scores + ((long)bh * p.seq_q) * p.seq_kv + kvrow;
+                // raw scores of this tile: lane part (its key, its 4 half rows) in one register, the row a scalar offset;
+                // rows beyond seq_q fall out of the descriptor's range and read 0.  Nontemporal (aux = 2): read once.
+                const int svoff = kvok ? (kvrow + 4 * half * p.seq_kv) * 4 : OOB;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = q0 + 4 * half + (r & 3) + 8 * (r >> 2);
-                    S[r] = (row < p.seq_q && kvok) ? ld_stream(sc + (long)row * p.seq_kv) : 0.f;
-                }
-#pragma unroll
-                for (int i = 0; i < NP; ++i) issue_piece(nq, nxt, i);
+                for (int r = 0; r < 16; ++r)
+                    S[r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, svoff, (q0 + (r & 3) + 8 * (r >> 2)) * srow_bytes, 2));
                 fa[0] = ld4(tDO + rb[0]);
             } else {
                 // ---- S[q, kv] = Q K^T: NG steps of (2 row reads, 4 MFMAs), every read one step ahead of its use;
@@ -537,8 +622,6 @@ mha_bwd_kernel(const MhaArgs p) {
                     } else {
                         fa[(g + 1) & 1] = ld4(tDO + rb[0]);                       // first fragment of the next phase
                     }
-#pragma unroll
-                    for (int i = g * NP / NG; i < (g + 1) * NP / NG; ++i) issue_piece(nq, nxt, i);
                     FENCE();
                     S = MFMA(fa[g & 1].x, fk[g & 1].x, S);
                     S = MFMA(fa[g & 1].y, fk[g & 1].y, S);
@@ -555,10 +638,6 @@ mha_bwd_kernel(const MhaArgs p) {
             for (int g = 0; g < NG; ++g) {
                 if (g + 1 < NG) fa[(F0 + g + 1) & 1] = ld4(tDO + rb[(g + 1) & 7] + T::row_imm(g + 1));
                 else ldv<VEC>(tDO + vb[0][0], ea[0]);                                 // first vector of the next phase
-                if (g < 4 && 8 * g < D) {              // old dQ^T values of head dimensions 8 g + 4 half .. of this wave's slice
-                    const u32x4_t o = __builtin_amdgcn_raw_buffer_load_b128(rsrcOld, dq_voff + 32 * g, dq_tile, 0);
-                    dq_old[g] = make_float4(__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w));
-                }
                 FENCE();
                 dP = MFMA(fa[(F0 + g) & 1].x, vf[g].x, dP);
                 dP = MFMA(fa[(F0 + g) & 1].y, vf[g].y, dP);
@@ -567,13 +646,17 @@ mha_bwd_kernel(const MhaArgs p) {
                 FENCE();
             }
             // ---- P = exp(scale S - LSE); dS = scale P (dP - delta), also into LDS for the dQ product
+            unsigned char mk[16];
+            if (MASK) {                                // mask bytes of this tile: one byte load each, row = scalar offset, no branch
+                const int mvoff = kvok ? kvrow + 4 * half * (int)p.mask_sq : OOB;
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    mk[r] = __builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff, (q0 + (r & 3) + 8 * (r >> 2)) * (int)p.mask_sq, 0);
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 float pr = fast_exp2(fmaf(S[r], c, -Lr[r]));
-                if (MASK) {
-                    const int qr = q0 + 4 * half + (r & 3) + 8 * (r >> 2);
-                    if (qr < p.seq_q && kvok && p.mask[b * p.mask_sb + h * p.mask_sh + (long)qr * p.mask_sq + kvrow] == 0) pr = 0.f;
-                }
+                if (MASK && mk[r] == 0) pr = 0.f;      // (a key or query beyond the end reads 0 too: its P is never used)
                 P[r] = pr;
                 dS[r] = pr * (dP[r] - Dr[r]) * p.scale;
                 sDS[ebs[(r >> 2) & 1][r & 3] + 8 * (r >> 2) * 128] = dS[r];
@@ -596,9 +679,7 @@ mha_bwd_kernel(const MhaArgs p) {
             STAMP(4);
 
             // ---- dQ[q, d] (+)= dS[q, kv] K[kv, d] over the 128 keys of the block; wave w takes the columns 32 w .. 32 w + 31
-            f32x16 acc;
             if (dq_wave) {
-                zero16(acc);
                 float4 da[2];
                 float dk4[2][4];
                 da[0] = ld4(sDS + rbs[0]);
@@ -613,6 +694,10 @@ mha_bwd_kernel(const MhaArgs p) {
                     } else {
                         ldv<VEC>(tQ + vb[0][0], ea[0]);                               // first vector of the next phase
                     }
+                    // The next tile's Q / dO pieces go out HERE: behind every load whose result this tile still waits for
+                    // (hipcc's counted waits do not see them), half a tile ahead of their use.
+                    if (g == 1) issue_half(nq, nxt, 0);
+                    if (g == 9) issue_half(nq, nxt, 1);
                     FENCE();
                     acc = MFMA(dk4[g & 1][0], da[g & 1].x, acc);      // transposed: rows = head dimension, column = query
                     acc = MFMA(dk4[g & 1][1], da[g & 1].y, acc);
@@ -621,6 +706,8 @@ mha_bwd_kernel(const MhaArgs p) {
                     FENCE();
                 }
             } else {
+                issue_half(nq, nxt, 0);
+                issue_half(nq, nxt, 1);
                 ldv<VEC>(tQ + vb[0][0], ea[0]);
             }
             STAMP(5);
@@ -636,8 +723,7 @@ mha_bwd_kernel(const MhaArgs p) {
                 if (r + 1 < 16) ldv<VEC>(tQ + vb[((r + 1) >> 2) & 1][(r + 1) & 3] + T::vec_imm(r + 1), ea[(r + 1) & 1]);
                 if ((r & 3) == 0 && 8 * (r >> 2) < D) {
                     const int g4 = r >> 2;
-                    const u32x4_t v = {__float_as_uint(acc[r] + dq_old[g4].x), __float_as_uint(acc[r + 1] + dq_old[g4].y),
-                                       __float_as_uint(acc[r + 2] + dq_old[g4].z), __float_as_uint(acc[r + 3] + dq_old[g4].w)};
+                    const u32x4_t v = {__float_as_uint(acc[r]), __float_as_uint(acc[r + 1]), __float_as_uint(acc[r + 2]), __float_as_uint(acc[r + 3])};
                     __builtin_amdgcn_raw_buffer_store_b128(v, rsrcDQw, dq_voff + 32 * g4, dq_tile, 0);
                 }
                 FENCE();
@@ -707,26 +793,42 @@ mha_delta_kernel(const float *__restrict__ dctx, long dctx_pitch, const float *_
     }
 }
 
+// The s_memtime stamps of npm_debug_attn_trace live in instances of their own (D = 128, no mask): the product
+// instances carry no trace code at all (each stamp is an exec-masked branch in a loop where every instruction counts).
+template <int D, bool MASK, bool SAVE>
+void launch_fwd_instance(const MhaArgs &a, int grid, hipStream_t s) {
+    if (D == 128 && !MASK && a.trace) hipLaunchKernelGGL((mha_fwd_kernel<D, MASK, SAVE, D == 128 && !MASK>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mha_fwd_kernel<D, MASK, SAVE, false>), dim3(grid), dim3(256), 0, s, a);
+}
+
 template <int D>
 int launch_fwd(const MhaArgs &a, hipStream_t s) {
     const int grid = a.batch * a.heads * a.q_tiles;
     const bool mask = a.mask != nullptr, save = a.scores != nullptr;
-    if (mask && save) hipLaunchKernelGGL((mha_fwd_kernel<D, true, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (mask) hipLaunchKernelGGL((mha_fwd_kernel<D, true, false>), dim3(grid), dim3(256), 0, s, a);
-    else if (save) hipLaunchKernelGGL((mha_fwd_kernel<D, false, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mha_fwd_kernel<D, false, false>), dim3(grid), dim3(256), 0, s, a);
+    if (mask && save) launch_fwd_instance<D, true, true>(a, grid, s);
+    else if (mask) launch_fwd_instance<D, true, false>(a, grid, s);
+    else if (save) launch_fwd_instance<D, false, true>(a, grid, s);
+    else launch_fwd_instance<D, false, false>(a, grid, s);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
+}
+
+template <int D, bool MASK, bool SAVED>
+void launch_bwd_instance(const MhaArgs &a, int grid, hipStream_t s) {
+    if (D == 128 && !MASK && a.trace) hipLaunchKernelGGL((mha_bwd_kernel<D, MASK, SAVED, D == 128 && !MASK>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((mha_bwd_kernel<D, MASK, SAVED, false>), dim3(grid), dim3(256), 0, s, a);
 }
 
 template <int D>
 int launch_bwd(const MhaArgs &a, hipStream_t s) {
     const int grid = a.batch * a.heads;
     const bool mask = a.mask != nullptr, saved = a.scores != nullptr;
-    if (mask && saved) hipLaunchKernelGGL((mha_bwd_kernel<D, true, true>), dim3(grid), dim3(256), 0, s, a);
-    else if (mask) hipLaunchKernelGGL((mha_bwd_kernel<D, true, false>), dim3(grid), dim3(256), 0, s, a);
-    else if (saved) hipLaunchKernelGGL((mha_bwd_kernel<D, false, true>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((mha_bwd_kernel<D, false, false>), dim3(grid), dim3(256), 0, s, a);
+    // Saved scores already CARRY the mask (the forward stored -inf at every masked position, so P = exp2(-inf) = 0
+    // there): the backward needs the mask bytes only when it recomputes q.k.  One instance less per head size -- the
+    // one whose 16 extra byte loads per tile did not fit the register file at D = 128.
+    if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
+    else if (mask) launch_bwd_instance<D, true, false>(a, grid, s);
+    else launch_bwd_instance<D, false, false>(a, grid, s);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }
@@ -754,6 +856,8 @@ int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
     a.mask = c->mask; a.mask_sb = c->mask_stride_b; a.mask_sh = c->mask_stride_h; a.mask_sq = c->mask_stride_q;
     a.scores = c->scores;
     NPM_ARG(!c->scores || al16(c->scores));
+    NPM_ARG(!c->scores || ((int64_t)c->seq_q + 32) * c->seq_kv * 4 < (1LL << 31));      // one (b, h) score matrix behind one descriptor
+    NPM_ARG(!c->mask || (c->mask_stride_q >= 0 && ((int64_t)c->seq_q + 32) * c->mask_stride_q + c->seq_kv < (1LL << 31)));
     a.batch = c->batch; a.heads = c->heads; a.seq_q = c->seq_q; a.seq_kv = c->seq_kv;
     a.scale = c->scale;
     a.q_tiles = (c->seq_q + 127) / 128;

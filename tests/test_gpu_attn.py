@@ -179,6 +179,58 @@ def test_core_masked(npm, b, h, sq, skv, d):
                 assert_close(got[name], want, tol=3e-6, what=name)
 
 
+@pytest.mark.parametrize('d', [16, 64, 128])
+def test_core_masks_that_hide_whole_leading_tiles(npm, d):
+    """Rows whose FIRST 32-key tile(s) are fully masked while later keys are allowed: sliding window (row i sees
+    keys [i - 8, i]), left padding (the first 40 keys excluded), block-diagonal.  The online softmax starts from
+    m = -inf there; np.where(mask, s, -inf) + softmax (attentions.py:105-109) gives finite values for these rows, so
+    must the kernel -- forward and backward, with saved scores and with recomputed ones."""
+    rng = np.random.default_rng(d)
+    b, h, sq, skv = 2, 2, 130, 136
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k, v = (rng.standard_normal([b, skv, h, d]).astype(np.float32) for _ in range(2))
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    i, j = np.arange(sq)[:, None], np.arange(skv)[None, :]
+    band = ((j <= i) & (j >= i - 8))[None, None]
+    left_pad = np.broadcast_to(j >= 40, (sq, skv))[None, None]
+    blocks = ((i // 48) == (j // 48))[None, None]
+    for name, mask in (('band', band), ('left padding', left_pad), ('block diagonal', blocks)):
+        full = np.broadcast_to(mask, (b, h, sq, skv))
+        assert full.any(axis=-1).all() and not full[..., :32].any(axis=-1).all()      # the case: leading tile hidden
+        ctx, lse, probs = O.attention_core_fwd(*(x.astype(np.float64) for x in (q, k, v)), scale, full)
+        dq, dk, dv = O.attention_core_bwd(*(x.astype(np.float64) for x in (q, k, v)), probs, dctx.astype(np.float64), scale)
+        for save in (False, True):
+            got = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save)
+            assert np.isfinite(got['ctx']).all() and np.isfinite(got['lse']).all(), name
+            assert_close(got['ctx'], ctx, tol=2e-6, what=name)
+            np.testing.assert_allclose(got['lse'], lse, rtol=0, atol=3e-6)
+            for g, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+                assert_close(got[g], want, tol=3e-6, what=f'{name} {g} save={save}')
+
+
+def test_core_row_without_any_key_is_nan_and_only_that_row(npm):
+    """A query row with NO key left is NaN, as the softmax of a row of -inf is in NumPy; every other row of the same
+    wave, tile and head is untouched (forward)."""
+    rng = np.random.default_rng(3)
+    b, h, sq, skv, d = 1, 2, 70, 96, 64
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k, v = (rng.standard_normal([b, skv, h, d]).astype(np.float32) for _ in range(2))
+    mask = np.ones([b, h, sq, skv], dtype=bool)
+    mask[0, 1, 37, :] = False
+    mask[0, 0, 5, :64] = False
+    scale = 1.0 / np.sqrt(d)
+    with np.errstate(invalid='ignore'):
+        ctx, lse, _ = O.attention_core_fwd(*(x.astype(np.float64) for x in (q, k, v)), scale, mask)
+    for save in (False, True):
+        got = _run_core(npm, q, k, v, scale, mask=mask, save=save)
+        assert np.isnan(got['ctx'][0, 37, 1]).all()
+        keep = np.ones([b, sq, h], dtype=bool)
+        keep[0, 37, 1] = False
+        assert np.isfinite(got['ctx'][keep]).all()
+        assert_close(got['ctx'][keep], ctx[keep], tol=2e-6)
+
+
 def test_core_rejects_unsupported_head_dim(npm):
     from np_modeling_amd import _C, device as D
     assert not D.mha_core_supported(24) and D.mha_core_supported(64) and not D.mha_core_supported(64, 32)
