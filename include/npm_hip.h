@@ -125,6 +125,7 @@ enum {
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */
     NPM_TUNE_GEMM_MATH = 10,         /* same as npm_set_math */
     NPM_TUNE_ATTN_STAGGER = 11,      /* attention forward: s_sleep(127) units one of the two blocks of a CU waits at its start (default 1) */
+    NPM_TUNE_CONV_WGRAD_FUSED = 13,  /* npm_conv2d_bwd_w_relu: 1 (default) ReLU backward inside the grad_w kernel, tile height picked; 2 / 3 the same with 128- / 192-row tiles; 0 two passes */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
     NPM_TUNE_GEMM_ABLATE = 99
 };
@@ -211,6 +212,14 @@ int npm_conv2d_bwd_x(const float *dy, const float *filt, float *dx,
 /* dw[i,j] = shifted(x)^T dy  (conv.py:185-194) */
 int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
                      int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
+/* Conv2D.backward's first three lines in one call (conv.py:54-56 with the layer's ReLU, activations.py:19):
+ *   g = where(pre >= 0, dy, 0)  [n,h,w,c_out], written out (the grad_x convolution reads it: npm_conv2d_bwd_x(g, ...))
+ *   db = sum over n, h, w of g  [c_out]
+ *   dw[i,j] = shifted(x)^T g    [k,k,c_in,c_out]
+ * The mask is applied where the grad_w kernel stages its dy tiles, so no separate ReLU-backward pass over the
+ * activation-sized tensors runs; results are bitwise reproducible (fixed-order slab and column reductions). */
+int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, float *g, float *dw, float *db,
+                          int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize);
 
 /* ---- fused attention core (layers/attentions.py:103-112 forward, :146-162 backward) ----
  * ctx[b, i, h, :] = sum_j softmax_j(scale * q[b, i, h, :] . k[b, j, h, :]) v[b, j, h, :] in ONE kernel: the

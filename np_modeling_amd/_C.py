@@ -122,6 +122,7 @@ SIGNATURES = {
     'npm_conv2d_fwd': [C.POINTER(npm_conv2d)],
     'npm_conv2d_bwd_x': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
     'npm_conv2d_bwd_w': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
+    'npm_conv2d_bwd_w_relu': [_P, _P, _P, _P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
     'npm_mha_core_supported': [C.c_int],
     'npm_mha_core_fwd': [C.POINTER(npm_mha_core)],
     'npm_mha_core_bwd': [C.POINTER(npm_mha_core)],

@@ -401,6 +401,218 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
     else write_tile(acc, e, raw, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
 
+// ---- grad_w with the ReLU backward inside (conv.py:54-56,185-194 in one launch) ---------------------------------
+// dw = gather(x)^T g with g = where(pre >= 0, dy, 0) (activations.py:19), db = sum over pixels of g (conv.py:55) and
+// g itself written out once for the grad_x convolution.  The standalone ReLU-backward pass (12 B per element of
+// [N, H, W, C1]: 3.7 of the 48 ms of config C3) is gone: the DENSE operand of this GEMM is staged through registers
+// (global -> registers -> mask -> LDS) instead of by LDS-DMA, which is where the mask is applied; the blocks of tile
+// row 0 also store g and sum its columns.  The gathered operand keeps the LDS-DMA path (from inline assembly,
+// npm_mfma_tile.h), with the image-border test hoisted out of the lanes: a K tile is 16 consecutive pixels, and
+// unless that run touches a border (or wraps to the next image row) every tap of every lane is in range -- a scalar
+// test per tile; only border tiles (15 % at 224 x 224) compute per-lane offsets.
+// Block tile (64 WR) x 128: waves 2 x 2, WR x 2 MFMA tiles per wave.  WR = 3 gives 192-row tiles: k*k*C0 = 576
+// is 3 of them exactly (4.5 tiles of 128 rows left a tenth of the MFMAs multiplying padding).
+// where(pre >= 0, dy, 0) on four elements: four compares into SGPR pairs, then four selects.  (Written out because
+// hipcc funnels such selects through VCC one at a time, with a wait-state s_nop between each compare and its select.)
+__device__ __forceinline__ float4 relu_mask4(const u32x4 &pre, const u32x4 &dy) {
+    float4 r;
+    unsigned long m0, m1, m2, m3;
+    asm("v_cmp_le_f32_e64 %4, 0, %8\n\tv_cmp_le_f32_e64 %5, 0, %9\n\tv_cmp_le_f32_e64 %6, 0, %10\n\tv_cmp_le_f32_e64 %7, 0, %11\n\t"
+        "v_cndmask_b32_e64 %0, 0, %12, %4\n\tv_cndmask_b32_e64 %1, 0, %13, %5\n\tv_cndmask_b32_e64 %2, 0, %14, %6\n\tv_cndmask_b32_e64 %3, 0, %15, %7"
+        : "=&v"(r.x), "=&v"(r.y), "=&v"(r.z), "=&v"(r.w), "=&s"(m0), "=&s"(m1), "=&s"(m2), "=&s"(m3)
+        : "v"(pre.x), "v"(pre.y), "v"(pre.z), "v"(pre.w), "v"(dy.x), "v"(dy.y), "v"(dy.z), "v"(dy.w));
+    return r;
+}
+
+struct WgradArgs {
+    const float *X, *DY, *PRE;
+    float *G;            // optional: the masked dy, [pixels, N]
+    float *colpart;      // optional: [splits][N] column sums of g per split
+    float *out;          // slabs [splits][M][N] (or dw itself when splits == 1)
+    int H, W, C, ks, pad;
+    int M, N, K;
+    int tiles_m, tiles_n, splits, k_per_split;
+    long slab;
+};
+
+template <int WR>
+__global__ void __launch_bounds__(NTHREADS, WR == 3 ? 3 : 4)
+conv_wgrad_relu_kernel(const WgradArgs p) {
+    constexpr int TM = 64 * WR, A_TILE = TM * GK, B_TILE = BN * GK, STAGE = A_TILE + B_TILE;
+    constexpr int PPW = TM / 64;                       // 1 KiB DMA pieces of the gathered tile per wave
+    constexpr int CPR = TM / 4;                        // 16-byte chunks per k row of the gathered tile
+    constexpr int OOB = 0x7FFFFFFF;
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int tiles = p.tiles_m * p.tiles_n;
+    const int t = logical % tiles, split = logical / tiles;
+    const int tm = t % p.tiles_m, tn = t / p.tiles_m;  // the tile rows of one (split, tn) are neighbours: they share dy / pre / x in L2
+    const int m0 = tm * TM, n0 = tn * BN;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(p.K, kbeg + p.k_per_split);
+    const int nkt = (kend - kbeg) / GK;
+    const bool first_row = tm == 0;                    // these blocks write g and sum its columns
+
+    // ---- gathered operand: descriptor over pixels [kbeg - halo, kend + halo)
+    const int halo = p.pad * p.W + p.pad;
+    const long first = (long)kbeg - halo;
+    const long last = min((long)kend + halo, (long)p.K);
+    const i32x4_t descA = make_desc(p.X + first * p.C, (last - first) * p.C * 4);
+    unsigned vfast[PPW];                               // in-image offsets (or out of range for rows beyond M)
+    int kr[PPW], di[PPW], dj[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int L = (wave * PPW + i) * 64 + lane;
+        kr[i] = L / CPR;
+        const int mq = m0 + 4 * (L - kr[i] * CPR);
+        const int tap = mq / p.C, c = mq - tap * p.C;
+        const int ti = tap / p.ks;
+        di[i] = ti - p.pad;
+        dj[i] = tap - ti * p.ks - p.pad;
+        vfast[i] = mq < p.M ? (unsigned)(((kr[i] + halo + di[i] * p.W + dj[i]) * p.C + c) * 4) : (unsigned)OOB;
+    }
+    const unsigned lds_a = lds_offset(smem + wave * PPW * 256);
+    // first pixel of the next tile to issue, as (row, column) of its image: scalars
+    int w0 = __builtin_amdgcn_readfirstlane(kbeg % p.W), h0 = __builtin_amdgcn_readfirstlane((kbeg / p.W) % p.H);
+
+    // ---- dense operand (dy, masked by pre): k rows (tid >> 5) and + 8, columns 4 (tid & 31) ..
+    const int ncol = n0 + 4 * (tid & 31);
+    const long rows_left = (long)(kend - kbeg);
+    const auto rsrcDY = __builtin_amdgcn_make_buffer_rsrc((void *)(p.DY + (long)kbeg * p.N), 0, (int)(rows_left * p.N * 4), 0x00020000);
+    const auto rsrcPRE = __builtin_amdgcn_make_buffer_rsrc((void *)(p.PRE + (long)kbeg * p.N), 0, (int)(rows_left * p.N * 4), 0x00020000);
+    const auto rsrcG = __builtin_amdgcn_make_buffer_rsrc((void *)((p.G ? p.G : p.out) + (long)kbeg * p.N), 0,
+                                                         (p.G && first_row) ? (int)(rows_left * p.N * 4) : 0, 0x00020000);
+    const int vb0 = ncol < p.N ? ((tid >> 5) * p.N + ncol) * 4 : OOB;
+    const int vb1 = ncol < p.N ? (((tid >> 5) + 8) * p.N + ncol) * 4 : OOB;
+    float *const sBw = smem + A_TILE + (tid >> 5) * BN + 4 * (tid & 31);      // + stage * STAGE (+ 8 BN for the second row)
+    const int tile_bytes = GK * p.N * 4;
+
+    f32x16 acc[WR][2];
+#pragma unroll
+    for (int i = 0; i < WR; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    float4 colacc = make_float4(0.f, 0.f, 0.f, 0.f);
+    u32x4 d0, d1, q0, q1;                               // dy and pre of the tile in flight
+    const int arow = wm * 32 * WR + l32, brow = wn * 64 + l32;
+
+    // issue tile KT: the gathered pieces by LDS-DMA into stage STG, the dense operand into registers
+#define NPM_WGRAD_ISSUE(KT, STG)                                                                                  \
+    do {                                                                                                          \
+        const bool interior = w0 + GK <= p.W - p.pad && w0 >= p.pad && h0 >= p.pad && h0 < p.H - p.pad;            \
+        const unsigned soff = (unsigned)((KT) * GK * p.C * 4);                                                     \
+        if (interior) {                                                                                            \
+            dma_group<PPW>(descA, lds_a + (STG) * STAGE * 4, soff, vfast);                                        \
+        } else {                                                                                                   \
+            unsigned v[PPW];                                                                                       \
+            _Pragma("unroll") for (int i = 0; i < PPW; ++i) {                                                      \
+                int w = w0 + kr[i], h = h0;                                                                        \
+                if (w >= p.W) { w -= p.W; h = h + 1 == p.H ? 0 : h + 1; }                                          \
+                const bool ok = (unsigned)(h + di[i]) < (unsigned)p.H && (unsigned)(w + dj[i]) < (unsigned)p.W;    \
+                v[i] = ok ? vfast[i] : (unsigned)OOB;                                                              \
+            }                                                                                                      \
+            dma_group<PPW>(descA, lds_a + (STG) * STAGE * 4, soff, v);                                            \
+        }                                                                                                          \
+        w0 += GK;                                                                                                  \
+        if (w0 >= p.W) { w0 -= p.W; h0 = h0 + 1 == p.H ? 0 : h0 + 1; }                                             \
+        d0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb0, (KT) * tile_bytes, 0);                             \
+        d1 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb1, (KT) * tile_bytes, 0);                             \
+        q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb0, (KT) * tile_bytes, 0);                            \
+        q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb1, (KT) * tile_bytes, 0);                            \
+    } while (0)
+    // mask the dense tile in flight (activations.py:19: x >= 0 keeps dy, x = 0 and -0 included), put it into
+    // stage STG; tile row 0 also writes it out as g and adds it to its column sums
+#define NPM_WGRAD_STAGE(KT, STG)                                                                                   \
+    do {                                                                                                           \
+        const float4 g0 = relu_mask4(q0, d0), g1 = relu_mask4(q1, d1);                                             \
+        *reinterpret_cast<float4 *>(sBw + (STG) * STAGE) = g0;                                                     \
+        *reinterpret_cast<float4 *>(sBw + (STG) * STAGE + 8 * BN) = g1;                                            \
+        if (first_row) {                                                                                           \
+            const u32x4 s0 = {__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)};  \
+            const u32x4 s1 = {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};  \
+            __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcG, vb0, (KT) * tile_bytes, 0);                          \
+            __builtin_amdgcn_raw_buffer_store_b128(s1, rsrcG, vb1, (KT) * tile_bytes, 0);                          \
+            colacc.x += g0.x + g1.x; colacc.y += g0.y + g1.y; colacc.z += g0.z + g1.z; colacc.w += g0.w + g1.w;     \
+        }                                                                                                          \
+    } while (0)
+
+    // one K tile: wait for it, issue the next one, multiply, stage the next one.  STG is a compile-time constant (the
+    // loop is unrolled by two): every LDS address is a loop-invariant register plus an immediate.
+#define NPM_WGRAD_TILE(KT, STG)                                                                                    \
+    do {                                                                                                           \
+        /* tile KT is in LDS for every wave (the DMA pieces: vmcnt; the masked rows: lgkmcnt); the other stage is   \
+           free.  The g stores of the tile before are this wave's youngest vector-memory operations: they stay in  \
+           flight. */                                                                                              \
+        if (first_row) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                            \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
+        __builtin_amdgcn_s_barrier();                                                                              \
+        asm volatile("" ::: "memory");                                                                             \
+        const bool more = (KT) + 1 < nkt;                                                                          \
+        if (more) NPM_WGRAD_ISSUE((KT) + 1, (STG) ^ 1);                                                            \
+        const float *sA = smem + (STG) * STAGE, *sB = sA + A_TILE;                                                 \
+        _Pragma("unroll") for (int g = 0; g < GK / 8; ++g) {                                                       \
+            float4 a[WR], b[2];                                                                                    \
+            _Pragma("unroll") for (int i = 0; i < WR; ++i) a[i] = read_frag16<false, TM>(sA, arow + 32 * i, g, half);   \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) b[j] = read_frag16<false, BN>(sB, brow + 32 * j, g, half);    \
+            _Pragma("unroll") for (int s = 0; s < 4; ++s)                                                          \
+            _Pragma("unroll") for (int i = 0; i < WR; ++i)                                                         \
+            _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                                        \
+                const float av = s == 0 ? a[i].x : s == 1 ? a[i].y : s == 2 ? a[i].z : a[i].w;                     \
+                const float bv = s == 0 ? b[j].x : s == 1 ? b[j].y : s == 2 ? b[j].z : b[j].w;                     \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i][j], 0, 0, 0);                      \
+            }                                                                                                      \
+        }                                                                                                          \
+        if (more) NPM_WGRAD_STAGE((KT) + 1, (STG) ^ 1);                                                            \
+    } while (0)
+
+    if (nkt > 0) {
+        NPM_WGRAD_ISSUE(0, 0);
+        NPM_WGRAD_STAGE(0, 0);
+    }
+    for (int kt = 0; kt < nkt; kt += 2) {
+        NPM_WGRAD_TILE(kt, 0);
+        if (kt + 1 < nkt) NPM_WGRAD_TILE(kt + 1, 1);
+    }
+#undef NPM_WGRAD_TILE
+#undef NPM_WGRAD_ISSUE
+#undef NPM_WGRAD_STAGE
+
+    // ---- raw accumulators into this split's slab (pitch N): one buffer store each, row = scalar offset
+    const int rows_here = min(p.M - m0, TM);
+    float *optr = p.out + (long)split * p.slab + (long)m0 * p.N;
+    const auto rsrcO = __builtin_amdgcn_make_buffer_rsrc((void *)optr, 0, (int)(((long)(rows_here - 1) * p.N + p.N) * 4), 0x00020000);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = n0 + wn * 64 + j * 32 + l32;
+        const int vc = col < p.N ? (4 * half * p.N + col) * 4 : OOB;
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rsrcO, vc,
+                                                      (wm * 32 * WR + i * 32 + (r & 3) + 8 * (r >> 2)) * p.N * 4, 0);
+    }
+    // ---- column sums of g over this split's pixels: the 8 k-row groups of the block through LDS, fixed order
+    if (first_row && p.colpart) {
+        __syncthreads();                                // every wave is done with the operand stages
+        *reinterpret_cast<float4 *>(smem + (tid >> 5) * BN + 4 * (tid & 31)) = colacc;
+        __syncthreads();
+        if (tid < BN) {
+            float total = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) total += smem[r * BN + tid];
+            if (n0 + tid < p.N) p.colpart[(long)split * p.N + n0 + tid] = total;
+        }
+    }
+}
+
 // out[(ti, tj, c1), c0] = filt[ks-1-ti, ks-1-tj, c0, c1]      (conv.py:130)
 __global__ void flip_transpose_filter_kernel(const float *__restrict__ filt, float *__restrict__ out,
                                              int ks, int c0, int c1) {
@@ -419,6 +631,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
 int g_conv_wave_prio = 0;   // NPM_TUNE_GEMM_WAVE_PRIO
 int g_conv_math = 0;        // NPM_TUNE_GEMM_MATH
+int g_wgrad_fused = 1;           // NPM_TUNE_CONV_WGRAD_FUSED: 0 two passes (ReLU backward, then grad_w), 1 fused (tile height picked), 2 / 3 fused with 128- / 192-row tiles
 int g_wgrad_blocks_per_cu = 0;   // NPM_TUNE_CONV_WGRAD_BLOCKS: 0 pick_splits chooses 3 or 4 blocks per CU, 3 / 4 pins it, -1 the old ceil(3 CUs / tiles)
 
 int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
@@ -466,6 +679,7 @@ extern "C" int npm_conv_set_dma(int on) { g_conv_dma = on; return NPM_OK; }
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu) { g_wgrad_blocks_per_cu = per_cu; return NPM_OK; }
 extern "C" int npm_conv_set_wave_prio(int bits) { g_conv_wave_prio = bits; return NPM_OK; }
 extern "C" int npm_conv_set_math(int mode) { g_conv_math = mode; return NPM_OK; }
+extern "C" int npm_conv_set_wgrad_fused(int mode) { g_wgrad_fused = mode; return NPM_OK; }
 
 extern "C" {
 
@@ -566,6 +780,84 @@ int npm_conv2d_bwd_w(const float *dy, const float *x, float *dw,
         return launch_splitk_reduce(r, s);
     }
     return NPM_OK;
+}
+
+/* dw, db and g = where(pre >= 0, dy, 0) of Conv2D.backward (conv.py:54-56 + activations.py:19) in one launch + the
+ * slab / column reductions; `g` feeds npm_conv2d_bwd_x.  Shapes the fused kernel does not take (channels not a
+ * multiple of 4, pixels not a multiple of 16, images narrower than 16, the split-bf16 math modes) run the two-pass
+ * form: npm_relu_bwd_colsum, then npm_conv2d_bwd_w. */
+int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, float *g, float *dw, float *db,
+                          int32_t n, int32_t h, int32_t w, int32_t c_in, int32_t c_out, int32_t ksize) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(n >= 0 && h >= 1 && w >= 1 && c_in >= 1 && c_out >= 1 && ksize >= 1 && ksize % 2 == 1);
+    NPM_ARG(dw != nullptr && db != nullptr);
+    const long pixels = (long)n * h * w;
+    NPM_ARG(pixels < (1L << 31) - BK);
+    if (pixels == 0) {
+        int rc = npm_fill_f32(dw, 0.f, (size_t)ksize * ksize * c_in * c_out);
+        return rc ? rc : npm_fill_f32(db, 0.f, (size_t)c_out);
+    }
+    NPM_ARG(dy && pre && x && g);
+    const int m = ksize * ksize * c_in;
+    const long halo = (long)(ksize / 2) * w + ksize / 2;
+    const bool fused = g_conv_dma && g_conv_math == 0 && g_wgrad_fused && c_in % 4 == 0 && c_out % 4 == 0 && pixels % GK == 0 && w >= GK &&
+                       aligned16(x) && aligned16(dy) && aligned16(pre) && aligned16(g) && (long)m * c_out * 4 < (1L << 31);
+    if (fused) {
+        WgradArgs a{};
+        a.X = x; a.DY = dy; a.PRE = pre; a.G = g;
+        a.H = h; a.W = w; a.C = c_in; a.ks = ksize; a.pad = ksize / 2;
+        a.M = m; a.N = c_out; a.K = (int)pixels;
+        // tile height: the one that pads k*k*C0 least (192-row tiles: 3 blocks per CU, 128-row tiles: 4)
+        const long pad128 = (long)((m + 127) / 128) * 128, pad192 = (long)((m + 191) / 192) * 192;
+        const bool tall = g_wgrad_fused == 3 || (g_wgrad_fused != 2 && pad192 < pad128);
+        const int tm_rows = tall ? 192 : 128, resident = tall ? 3 : 4;
+        a.tiles_m = (m + tm_rows - 1) / tm_rows;
+        a.tiles_n = (c_out + BN - 1) / BN;
+        const long tiles = (long)a.tiles_m * a.tiles_n;
+        const int nkt = (int)(pixels / GK);
+        int splits = 1;
+        if (tiles < 2L * npm::ctx().num_cus && nkt >= 16)
+            splits = pick_splits(tiles, nkt, npm::ctx().num_cus, g_wgrad_blocks_per_cu > 0 ? g_wgrad_blocks_per_cu : 0, resident);
+        splits = std::max(1, splits);
+        const int kt_per = (nkt + splits - 1) / splits;
+        splits = (nkt + kt_per - 1) / kt_per;
+        a.splits = splits;
+        a.k_per_split = kt_per * GK;
+        const bool fits = ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) && (long)a.k_per_split * c_out * 4 < (1L << 30) &&
+                          tiles * splits < (1L << 31);
+        if (fits) {
+            npm::Scratch ws, parts;
+            int rc = parts.alloc(sizeof(float) * (size_t)splits * c_out);
+            if (rc) return rc;
+            a.colpart = (float *)parts.ptr;
+            a.slab = (long)m * c_out;
+            if (splits > 1) {
+                rc = ws.alloc(sizeof(float) * (size_t)a.slab * splits);
+                if (rc) return rc;
+                a.out = (float *)ws.ptr;
+            } else {
+                a.out = dw;
+            }
+            hipStream_t s = npm::ctx().stream;
+            npm::note_math(0);
+            const int grid = (int)(tiles * splits);
+            if (tall) hipLaunchKernelGGL(conv_wgrad_relu_kernel<3>, dim3(grid), dim3(NTHREADS), 0, s, a);
+            else hipLaunchKernelGGL(conv_wgrad_relu_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
+            NPM_CHECK_LAUNCH();
+            if (splits > 1) {
+                ReduceArgs r{};
+                r.ws = a.out; r.slab = a.slab; r.splits = splits;
+                r.M = m; r.N = c_out; r.batch1 = 1;
+                r.e.C = dw; r.e.ldc = c_out; r.e.alpha = 1.f;
+                rc = launch_splitk_reduce(r, s);
+                if (rc) return rc;
+            }
+            return npm_colsum(a.colpart, db, splits, c_out, c_out);       // fixed order over the splits
+        }
+    }
+    int rc = npm_relu_bwd_colsum(pre, dy, g, db, pixels, c_out);
+    if (rc) return rc;
+    return npm_conv2d_bwd_w(g, x, dw, n, h, w, c_in, c_out, ksize);
 }
 
 }  // extern "C"

@@ -411,6 +411,7 @@ extern "C" int npm_conv_set_dma(int on);
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
 extern "C" int npm_conv_set_wave_prio(int bits);
 extern "C" int npm_conv_set_math(int mode);
+extern "C" int npm_conv_set_wgrad_fused(int mode);
 extern "C" int npm_attn_set_stagger(int units);
 
 extern "C" int npm_set_math(int mode) { return npm_set_tuning(NPM_TUNE_GEMM_MATH, mode); }
@@ -426,6 +427,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_GEMM_BUF_EPILOGUE: g_buf_epilogue = value; return NPM_OK;
         case NPM_TUNE_CONV_DMA: return npm_conv_set_dma(value);
         case NPM_TUNE_CONV_WGRAD_BLOCKS: return npm_conv_set_wgrad_blocks(value);
+        case NPM_TUNE_CONV_WGRAD_FUSED: return npm_conv_set_wgrad_fused(value);
         case NPM_TUNE_GEMM_MATH:
             if (value < 0 || value > 3) return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: NPM_TUNE_GEMM_MATH takes 0, 1, 2 or 3");
             g_math = value;

@@ -419,6 +419,72 @@ __device__ __forceinline__ void dma_barrier() {
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// LDS-DMA issued from inline assembly.  Through the builtin, hipcc (ROCm 7.2) knows that an LDS-DMA piece is a
+// pending LDS write on the vector-memory counter and puts `s_waitcnt vmcnt(0)` in front of the next ds_read in the same
+// basic block -- i.e. right after the NEXT tile's pieces were issued it waits for them, and every other outstanding
+// load, before reading the CURRENT tile: the prefetch never overlapped anything (the attention kernels of round 2 had that wait;
+// whether it appears depends on the control flow between issue and read).  These pipelines order their stages
+// themselves (a counted `s_waitcnt vmcnt` + the workgroup barrier at the top of every tile), so the pieces are
+// invisible to the compiler: no wait of its own, no VALU for the addresses (the tile offset is the SCALAR offset of
+// the instruction, range-checked together with the lane's offset), M0 saved and restored around each group.
+// hipcc's counted waits for its OWN loads do not see these pieces; a piece issued after such a load only makes that
+// wait stricter than needed (loads return in order), never too lax.
+// ---------------------------------------------------------------------------------------------------------------
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ i32x4_t make_desc(const void *base, long bytes) {      // the words of make_rsrc, in SGPRs
+    const unsigned long a = (unsigned long)base;
+    i32x4_t d;
+    d.x = __builtin_amdgcn_readfirstlane((int)a);
+    d.y = __builtin_amdgcn_readfirstlane((int)(a >> 32) & 0xffff);
+    d.z = __builtin_amdgcn_readfirstlane((int)(bytes < 0 ? 0 : bytes > 0x7FFFFFF0L ? 0x7FFFFFF0L : bytes));
+    d.w = 0x00020000;
+    return d;
+}
+__device__ __forceinline__ unsigned lds_offset(const float *p) {                  // byte address inside LDS (wave-uniform)
+    return __builtin_amdgcn_readfirstlane((unsigned)(unsigned long)(lds_void *)p);
+}
+
+// N consecutive 1 KiB pieces starting at LDS byte address `lds`: piece i copies 16 bytes per lane from
+// (desc, voff[i] + soff).  The wait state between a write of M0 and the instruction that reads it is the s_nop.
+#define NPM_DMA_FIRST "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+#define NPM_DMA_NEXT "s_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+#define NPM_DMA_LOAD(v) "buffer_load_dwordx4 " v ", %2, %3 offen lds\n\t"
+#define NPM_DMA_LAST "s_mov_b32 m0, %0"
+__device__ __forceinline__ void dma_group1(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_group2(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0, unsigned v1) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_NEXT NPM_DMA_LOAD("%5") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0), "v"(v1) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_group3(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0, unsigned v1, unsigned v2) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_NEXT NPM_DMA_LOAD("%5") NPM_DMA_NEXT NPM_DMA_LOAD("%6") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0), "v"(v1), "v"(v2) : "memory", "scc");
+}
+__device__ __forceinline__ void dma_group4(i32x4_t desc, unsigned lds, unsigned soff, unsigned v0, unsigned v1, unsigned v2, unsigned v3) {
+    unsigned keep;
+    asm volatile(NPM_DMA_FIRST NPM_DMA_LOAD("%4") NPM_DMA_NEXT NPM_DMA_LOAD("%5") NPM_DMA_NEXT NPM_DMA_LOAD("%6") NPM_DMA_NEXT NPM_DMA_LOAD("%7") NPM_DMA_LAST
+                 : "=&s"(keep) : "s"(lds), "s"(desc), "s"(soff), "v"(v0), "v"(v1), "v"(v2), "v"(v3) : "memory", "scc");
+}
+template <int N>
+__device__ __forceinline__ void dma_group(i32x4_t desc, unsigned lds, unsigned soff, const unsigned (&v)[N]) {
+    static_assert(N == 1 || N == 2 || N == 3 || N % 4 == 0, "pieces per wave");
+    if constexpr (N == 1) dma_group1(desc, lds, soff, v[0]);
+    else if constexpr (N == 2) dma_group2(desc, lds, soff, v[0], v[1]);
+    else if constexpr (N == 3) dma_group3(desc, lds, soff, v[0], v[1], v[2]);
+    else {
+#pragma unroll
+        for (int i = 0; i < N; i += 4) dma_group4(desc, lds + i * 1024, soff, v[i], v[i + 1], v[i + 2], v[i + 3]);
+    }
+}
+
+
 // WIDTH: rows (K-major) / floats per k row (MN-major) of the operand tile: 128, or 256 for the wide tile.
 template <bool KMAJ, int WIDTH = BM>
 __device__ __forceinline__ unsigned glds_voffset(int lane, int j, long ld) {

@@ -71,15 +71,20 @@ class Conv2D(layer.StatefulLayer):
         k, c1 = self._kernel_size, self._output_channels
         with parallel.grad_scope(w.size + c1 + 8) as scope:
             db = scope.take([c1])
-            if self._fused_relu():           # relu' and db (conv.py:54-55) in one pass over dy
-                g = D.relu_bwd_colsum(self._activation._x, dy, c1, db)
+            dw = scope.take(w.shape)
+            flops = 2.0 * n * h * wd * c1 * k * k * c0
+            if self._fused_relu():
+                # relu' (activations.py:19), db and dw (conv.py:54-56) in one call: the mask is applied where the
+                # filter-gradient kernel stages its dy tiles; g = relu'(dy) comes back for the grad_x convolution
+                g = D.empty(dy.shape)
+                with D._timed('conv2d_bwd_w', flops, nbytes=4.0 * (3 * g.size + x.size)):
+                    _C.check(_C.lib().npm_conv2d_bwd_w_relu(dy.ptr, self._activation._x.ptr, x.ptr, g.ptr, dw.ptr, db.ptr,
+                                                           n, h, wd, c0, c1, k), 'npm_conv2d_bwd_w_relu')
             else:
                 g = D.as_device(self._activation.backward(dy))
                 D.colsum(g, n * h * wd, c1, out=db)
-            dw = scope.take(w.shape)
-            flops = 2.0 * n * h * wd * c1 * k * k * c0
-            with D._timed('conv2d_bwd_w', flops):
-                _C.check(_C.lib().npm_conv2d_bwd_w(g.ptr, x.ptr, dw.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_w')
+                with D._timed('conv2d_bwd_w', flops):
+                    _C.check(_C.lib().npm_conv2d_bwd_w(g.ptr, x.ptr, dw.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_w')
             dx = D.empty(x.shape)
             with D._timed('conv2d_bwd_x', flops):
                 _C.check(_C.lib().npm_conv2d_bwd_x(g.ptr, w.ptr, dx.ptr, n, h, wd, c0, c1, k), 'npm_conv2d_bwd_x')

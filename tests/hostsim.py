@@ -313,6 +313,12 @@ class HostSim:
         _vec(dw, k * k * c0 * c1)[:] = O.conv2d_grad_w(g, xv, k).ravel()
         return 0
 
+    def npm_conv2d_bwd_w_relu(self, dy, pre, x, g, dw, db, n, h, w, c0, c1, k):
+        size = n * h * w * c1
+        gv = np.where(_vec(pre, size) >= 0, _vec(dy, size), 0).astype(np.float32)
+        _vec(g, size)[:] = gv
+        _vec(db, c1)[:] = gv.reshape(-1, c1).sum(axis=0)
+        return self.npm_conv2d_bwd_w(g, x, dw, n, h, w, c0, c1, k)
 
     # ---- around the path -------------------------------------------------------------------------
     def npm_fill_f64(self, dst, value, n):

@@ -107,6 +107,61 @@ def test_conv_random_sweep(npm, math_mode):
         assert_close(gw, O.conv2d_grad_w(dy64, x64, k), tol=5e-6, what=what + ' grad_w')
 
 
+@pytest.mark.parametrize('fused', [1, 2, 3, 0])
+@pytest.mark.parametrize('n,h,w,c0,c1,k', [
+    (2, 16, 16, 64, 128, 3),       # C3 channel counts: M = 576 = 3 x 192 rows
+    (1, 32, 48, 4, 20, 3),         # M = 36 (one ragged tile), N = 20 (ragged columns)
+    (3, 16, 32, 16, 132, 1),       # k = 1: no halo; N = 132: two column tiles, the second ragged
+    (2, 24, 16, 8, 16, 5),         # k = 5: two-pixel halo, image exactly one K tile wide
+    (4, 40, 40, 32, 64, 3),        # rows that wrap inside a K tile (40 is not a multiple of 16): per-lane offsets
+    (64, 32, 16, 32, 16, 3),       # reference conv_test.py shape
+    (1, 5, 7, 3, 5, 3), (2, 6, 10, 4, 8, 3),      # off the fused path: channels / pixels / width
+])
+def test_conv_bwd_w_relu(npm, n, h, w, c0, c1, k, fused):
+    """npm_conv2d_bwd_w_relu = the first three lines of Conv2D.backward (conv.py:54-56 with activations.py:19): g,
+    db and dw from dy, the saved pre-activation and x, with the ReLU mask applied inside the filter-gradient kernel
+    (NPM_TUNE_CONV_WGRAD_FUSED 1: tile height picked, 2 / 3: 128- / 192-row tiles, 0: the two-pass form).  The mask
+    is exact at pre = +0 and -0 (x >= 0 keeps dy); g and db are bit-equal to the elementwise reference."""
+    from np_modeling_amd import _C, device as D
+    lib = _C.lib()
+    rng = np.random.default_rng(n * 7 + h + c1 + k)
+    x = rng.standard_normal((n, h, w, c0)).astype(np.float32)
+    dy = rng.standard_normal((n, h, w, c1)).astype(np.float32)
+    pre = rng.standard_normal((n, h, w, c1)).astype(np.float32)
+    pre.reshape(-1)[::7] = 0.0
+    pre.reshape(-1)[3::11] = -0.0
+    guard = 96
+    gbuf, dwbuf, dbbuf = D.full([dy.size + guard], 777.0), D.full([k * k * c0 * c1 + guard], 777.0), D.full([c1 + guard], 777.0)
+    ddy, dpre, dx_ = D.from_host(dy), D.from_host(pre), D.from_host(x)          # (kept alive: the pool reuses freed blocks)
+    _C.check(lib.npm_set_tuning(13, fused), 'npm_set_tuning')
+    try:
+        _C.check(lib.npm_conv2d_bwd_w_relu(ddy.ptr, dpre.ptr, dx_.ptr, gbuf.ptr, dwbuf.ptr, dbbuf.ptr, n, h, w, c0, c1, k),
+                 'npm_conv2d_bwd_w_relu')
+    finally:
+        _C.check(lib.npm_set_tuning(13, 1), 'npm_set_tuning')
+    want_g = np.where(pre >= 0, dy, 0).astype(np.float32)
+    for buf, size in ((gbuf, dy.size), (dwbuf, k * k * c0 * c1), (dbbuf, c1)):
+        np.testing.assert_array_equal(buf.numpy()[size:], 777.0)          # nothing written past the end
+    np.testing.assert_array_equal(gbuf.numpy()[:dy.size].reshape(dy.shape), want_g)
+    assert_close(dbbuf.numpy()[:c1], want_g.astype(np.float64).reshape(-1, c1).sum(axis=0), tol=3e-6)
+    assert_close(dwbuf.numpy()[:k * k * c0 * c1].reshape(k, k, c0, c1),
+                 O.conv2d_grad_w(want_g.astype(np.float64), x.astype(np.float64), k), tol=5e-6)
+
+
+def test_conv_bwd_w_relu_is_deterministic(npm):
+    from np_modeling_amd import _C, device as D
+    rng = np.random.default_rng(5)
+    n, h, w, c0, c1, k = 8, 32, 32, 64, 128, 3
+    x, dy, pre = (D.from_host(rng.standard_normal(s).astype(np.float32)) for s in ((n, h, w, c0), (n, h, w, c1), (n, h, w, c1)))
+    runs = []
+    for _ in range(2):
+        g, dw, db = D.empty([n, h, w, c1]), D.empty([k, k, c0, c1]), D.empty([c1])
+        _C.check(_C.lib().npm_conv2d_bwd_w_relu(dy.ptr, pre.ptr, x.ptr, g.ptr, dw.ptr, db.ptr, n, h, w, c0, c1, k))
+        runs.append((dw.numpy(), db.numpy()))
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])
+
+
 def test_conv_rejects_even_kernel(npm):
     layer = npm.layers.Conv2D(channels=4, kernel_size=2)
     with pytest.raises(AssertionError):
