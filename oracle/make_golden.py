@@ -168,6 +168,24 @@ def gen_losses(loss):
          ce=np.float64(ce_value), ce_grad=ce_grad)
 
 
+def gen_softmax_ce(layers, loss):
+    """loss_test.py:49-66: the composed flow ``ce(softmax(y), t)`` forward and
+    ``softmax(ce(y, t, backprop=True), backprop=True)`` backward, with soft targets (a softmax of noise, as the test
+    draws them).  Note the call form: the loss's backward ignores its positional arguments and uses what its
+    forward cached (loss.py:33-39)."""
+    np.random.seed(0)
+    y = rand([128, 32])
+    noise = rand([128, 32])
+    targets = (np.exp(noise) / np.exp(noise).sum(axis=-1, keepdims=True)).astype(np.float32)
+    ce = loss.CrossEntropyLoss()
+    softmax = layers.Softmax()
+    prob = softmax(y)
+    value = ce(prob, targets)
+    dprob = ce(y, targets, backprop=True)
+    dy = softmax(dprob, backprop=True)
+    save('softmax_ce', y=y, targets=targets, prob=prob, ce=np.float64(value), dprob=dprob, dy=dy)
+
+
 def gen_train(layers, optimizer, train):
     """train_test.py:14-49 flow; the printed losses are the known answers."""
     import re
@@ -207,6 +225,7 @@ def main():
     gen_decoder(layers, True, 'decoder_prenorm')
     gen_decoder(layers, False, 'decoder_postnorm')
     gen_losses(loss)
+    gen_softmax_ce(layers, loss)
     gen_train(layers, optimizer, train)
 
 

@@ -214,6 +214,26 @@ def test_losses_on_device(npm):
     assert_close(ce(backprop=True), g['ce_grad'], tol=1e-6)
 
 
+def test_softmax_cross_entropy_chain_on_device(npm):
+    """reference loss_test.py:49-66, the composed flow in its own call form: ``ce(softmax(y), t)`` and
+    ``softmax(ce(y, t, backprop=True), backprop=True)`` -- the loss's backward ignores the arguments it is called
+    with and uses what its forward cached; everything stays on the device between the two layers."""
+    g = load_golden('softmax_ce')
+    ce, softmax = npm.loss.CrossEntropyLoss(), npm.layers.Softmax()
+    y = npm.as_device(g['y'])
+    prob = softmax(y)
+    assert isinstance(prob, npm.DeviceArray)
+    assert_close(prob, g['prob'], tol=1e-6)
+    np.testing.assert_allclose(ce(prob, g['targets']), g['ce'], rtol=1e-6)
+    dprob = ce(y, g['targets'], backprop=True)
+    assert isinstance(dprob, npm.DeviceArray)
+    assert_close(dprob, g['dprob'], tol=1e-6)
+    dy = softmax(dprob, backprop=True)
+    assert_close(dy, g['dy'], tol=2e-6)
+    prob64 = g['prob'].astype(np.float64)
+    assert_close(dy, prob64 * g['targets'].astype(np.float64).sum(axis=-1, keepdims=True) - g['targets'], tol=2e-6)
+
+
 def test_adam_on_device_matches_reference_numerics(npm):
     """Three Adam steps on device-resident fp64 moments against the oracle's restatement of
     reference optimizer.py:53-67 (epsilon inside the sqrt, bias correction)."""

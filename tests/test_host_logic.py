@@ -501,6 +501,18 @@ def test_loss_broadcasts_resident_targets(npm, capsys):
     assert capsys.readouterr().out.count('Loss:') == 2
 
 
+def test_softmax_cross_entropy_chain_on_simulator(npm):
+    """loss_test.py:49-66 through the product's host layer (call protocol of Layer.__call__ with backprop=True on a
+    loss and on an activation that takes no optimizer)."""
+    g = load_golden('softmax_ce')
+    ce, softmax = npm.loss.CrossEntropyLoss(), npm.layers.Softmax()
+    y = npm.as_device(g['y'])
+    prob = softmax(y)
+    np.testing.assert_allclose(ce(prob, g['targets']), g['ce'], rtol=1e-6)
+    dy = softmax(ce(y, g['targets'], backprop=True), backprop=True)
+    assert_close(dy, g['dy'], tol=2e-6)
+
+
 def test_pick_device_policy():
     """One process per GPU under either kind of launcher: all GPUs visible -> LOCAL_RANK; devices masked per rank
     (one visible) -> device 0; NPM_DEVICE wins; a mask that is neither is an error, not a silent share."""

@@ -194,6 +194,21 @@ def test_losses():
     close(O.xent_bwd(g['prob'], g['onehot']), g['ce_grad'])
 
 
+@pytest.mark.parametrize('verbatim', [True, False])
+def test_softmax_cross_entropy_chain(verbatim):
+    """loss_test.py:49-66: ce(softmax(y), t) forward, softmax.backward(ce.backward()) backward; the closed form
+    of the composition is the textbook softmax(y) * sum(t) - t."""
+    g = load_golden('softmax_ce')
+    prob = O.softmax_fwd(g['y'])
+    close(prob, g['prob'])
+    np.testing.assert_allclose(O.xent_fwd(prob, g['targets']), g['ce'], rtol=1e-6)
+    dprob = O.xent_bwd(prob, g['targets'])
+    close(dprob, g['dprob'], rtol=1e-5, atol=1e-4)
+    dy = O.softmax_bwd(prob, dprob, verbatim=verbatim)
+    close(dy, g['dy'], rtol=1e-5, atol=1e-6)
+    close(dy, prob * g['targets'].sum(axis=-1, keepdims=True) - g['targets'], rtol=1e-5, atol=1e-6)
+
+
 def test_attention_core_restatements_agree():
     """The one-shot attention core (attentions.py:103-112) and the blockwise online-softmax forward the reference
     derives in attentions_test.py:194-246 are the same function; the core composed with the projections is
