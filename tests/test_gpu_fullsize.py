@@ -339,3 +339,111 @@ def test_conv_c3_slice(npm):
             del gprobe
     finally:
         npm.set_math('f32')
+
+
+_DEC_PARAMS = dict(n1_gamma=('_norm1', '_gamma'), n1_beta=('_norm1', '_beta'), n2_gamma=('_norm2', '_gamma'),
+                   n2_beta=('_norm2', '_beta'), n3_gamma=('_norm3', '_gamma'), n3_beta=('_norm3', '_beta'),
+                   d1_w=('_dense1._linear', '_w'), d1_b=('_dense1._linear', '_b'), d2_w=('_dense2', '_w'), d2_b=('_dense2', '_b'))
+for _n in O.MHA_PARAM_NAMES:
+    _DEC_PARAMS['sa_' + _n] = ('_self_attention', '_' + _n)
+    _DEC_PARAMS['ca_' + _n] = ('_cross_attention', '_' + _n)
+
+
+def _decoder(npm, rng, norm_first):
+    """TransformerDecoder at d_model 1024 / 8 heads / U 4096 with O(1) activations: weight matrices drawn like the
+    reference's initializer and scaled by 1 / sqrt(fan_in), biases and LayerNorm parameters as drawn."""
+    dec = npm.layers.TransformerDecoder(num_heads=H, hidden_units=U, norm_first=norm_first)
+    dec(npm.as_device(np.zeros([1, 8, F], dtype=np.float32)), npm.as_device(np.zeros([1, 8, F], dtype=np.float32)))
+    p = {}
+    for key, (path, attr) in _DEC_PARAMS.items():
+        obj = dec
+        for part in path.split('.'):
+            obj = getattr(obj, part)
+        arr = getattr(obj, attr)
+        fan_in = U if key == 'd2_w' else F
+        scale = 1 / np.sqrt(fan_in) if arr.ndim > 1 else 1.0
+        new = (np.clip(rng.standard_normal(arr.shape), -1, 1) * scale).astype(np.float32)
+        arr.set(new)
+        p[key] = new.astype(np.float64)
+    return dec, p
+
+
+@pytest.mark.parametrize('norm_first', [True, False])
+def test_decoder_slice(npm, norm_first):
+    """TransformerDecoder (reference transformer.py:95-203) AT SIZE: batch 64, Sq 512, Skv 1024 (cross-attention with
+    Sq != Skv at head size 128 through the fused core, inside the layer), d_model 1024, 8 heads, U 4096.
+      * two samples of the full-size run against the oracle at O(1) activations (every op is per sample);
+      * the 26 parameter gradients are additive over batch halves;
+      * the fused composition (residuals / dkey + dvalue / dq + dk + dv in GEMM epilogues and the LayerNorm backward)
+        equals the literal reference order built from standalone kernels."""
+    from np_modeling_amd import parallel
+    D = npm.device
+    b, sq, skv = 64, 512, 1024
+    rng = np.random.default_rng(11 + int(norm_first))
+    dec, p = _decoder(npm, rng, norm_first)
+    q = rng.standard_normal([b, sq, F], dtype=np.float32)
+    kv = rng.standard_normal([b, skv, F], dtype=np.float32)
+    dy = rng.standard_normal([b, sq, F], dtype=np.float32) * np.float32(0.01)
+    dq_, dkv_, ddy = D.from_host(q), D.from_host(kv), D.from_host(dy)
+
+    rec_full = GradRecorder()
+    out = dec(dq_, dkv_)
+    assert dec._cross_attention._core and dec._self_attention._core            # the fused attention core ran
+    gq, gkv = dec(ddy, backprop=True, optimizer_=rec_full)
+    out_host = out.numpy()
+    gq_host, gkv_host = gq.numpy(), gkv.numpy()
+    full = {k: np.asarray(v).astype(np.float64) for k, v in rec_full.grads.items()}
+    assert len(full) == 26
+
+    # (1) a batch slice of the full-size run == that slice alone, by the oracle
+    sl = slice(30, 32)
+    want_out, cache = O.decoder_fwd(p, q[sl].astype(np.float64), kv[sl].astype(np.float64), norm_first)
+    assert_close(out_host[sl], want_out, tol=1e-5)
+    # ReLU's derivative is discontinuous: a hidden pre-activation within fp32 rounding of 0 may take the other branch
+    # than in the fp64 oracle, and in a decoder that one row's gradient reaches every key through the cross-attention.
+    # So the oracle's backward runs on the kernel's OWN branch decisions -- after checking that the kernel's
+    # pre-activations are the oracle's and that every differing decision sits inside the rounding band.
+    pre_gpu = dec._dense1._activation._x.flat_view(sl.start * sq * U, [2 * sq, U]).numpy()
+    assert_close(pre_gpu, cache['d1_pre'], tol=1e-5)
+    flips = (pre_gpu >= 0) != (cache['d1_pre'] >= 0)
+    assert flips.mean() < 1e-4 and (np.abs(cache['d1_pre'][flips]) < 5e-6).all()
+    cache['d1_pre'] = pre_gpu.astype(np.float64)
+    (want_dq, want_dkv), _ = O.decoder_bwd(p, cache, dy[sl].astype(np.float64), norm_first)
+    assert_close(gq_host[sl], want_dq, tol=1e-5)
+    assert_close(gkv_host[sl], want_dkv, tol=1e-5)
+
+    # (2) parameter gradients are additive over batch halves
+    acc = {}
+    for lo, hi in ((0, b // 2), (b // 2, b)):
+        rec = GradRecorder()
+        dec(D.from_host(q[lo:hi]), D.from_host(kv[lo:hi]))
+        dec(D.from_host(dy[lo:hi]), backprop=True, optimizer_=rec)
+        for k, v in rec.grads.items():
+            acc[k] = acc.get(k, 0) + np.asarray(v).astype(np.float64)
+    bq_scale = max(np.abs(v).max() for k, v in full.items() if k[1] == '_bq')
+    for k in full:
+        if k[1] == '_bk':              # exactly zero in real arithmetic (rows of datt sum to 0): rounding noise
+            assert np.abs(full[k]).max() < 1e-4 * bq_scale and np.abs(acc[k]).max() < 1e-4 * bq_scale
+            continue
+        assert_close(full[k], acc[k], tol=2e-5, what=str(k[:2]))
+
+    # (3) fused == unfused, on a quarter of the batch
+    n = b // 4
+    xq, xkv, xdy = D.from_host(q[:n]), D.from_host(kv[:n]), D.from_host(dy[:n])
+    o1 = dec(xq, xkv).numpy()
+    r1 = GradRecorder()
+    dq1, dkv1 = (g.numpy() for g in dec(xdy, backprop=True, optimizer_=r1))
+    o2 = dec._forward_unfused(xq, xkv).numpy()
+    assert_close(o1, o2, tol=3e-6)
+    r2 = GradRecorder()
+    with parallel.grad_scope(0) as scope:
+        dq2, dkv2 = (g.numpy() for g in dec._backward_unfused(xdy, r2, scope))
+    assert_close(dq1, dq2, tol=1e-5)
+    assert_close(dkv1, dkv2, tol=1e-5)
+    assert r1.grads.keys() == r2.grads.keys()
+    for k in r1.grads:
+        a, c2 = np.asarray(r1.grads[k]), np.asarray(r2.grads[k])
+        if k[1] == '_bk':
+            assert np.abs(a).max() < 1e-4 * bq_scale and np.abs(c2).max() < 1e-4 * bq_scale
+            continue
+        assert_close(a, c2, tol=1e-5, what=str(k[:2]))

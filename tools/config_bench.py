@@ -22,6 +22,7 @@ import numpy as np  # noqa: E402
 PEAK = 157.3
 MIN_SECONDS = 0.5
 NAMES = ('C2', 'C3', 'C4')
+EXTRA = ('DEC',)          # not a BASELINE.json config: TransformerDecoder at size, `--only DEC`
 
 
 def timed(fn, steps, D, min_seconds=None, kernels=False):
@@ -94,6 +95,30 @@ def build_config(name, npm, D, rng, conv_batch=256):
             setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
         label = 'MultiHeadAttention d_model=1024 heads=8 seq=512 fwd+bwd+SGD, batch 256 (BASELINE.json configs[3])'
         flops = 12 * 2.0 * b * s * f * f + 6 * 2.0 * b * s * s * f
+    elif name == 'DEC':
+        b, sq, skv, f, h, u = 64, 512, 1024, 1024, 8, 4096
+        layer = npm.layers.TransformerDecoder(num_heads=h, hidden_units=u, norm_first=True)
+        x = D.from_host(rng.standard_normal([b, sq, f], dtype=np.float32))
+        kv = D.from_host(rng.standard_normal([b, skv, f], dtype=np.float32))
+        dy = D.from_host(rng.standard_normal([b, sq, f], dtype=np.float32) * np.float32(0.01))
+        layer(x, kv)
+        for att in (layer._self_attention, layer._cross_attention):
+            for n in ('_wq', '_wk', '_wv', '_wo'):
+                setattr(att, n, (np.asarray(getattr(att, n)) / 32).astype(np.float32))
+        layer._dense1._linear._w = (np.asarray(layer._dense1._linear._w) / 32).astype(np.float32)
+        layer._dense2._w = (np.asarray(layer._dense2._w) / 64).astype(np.float32)
+        label = (f'TransformerDecoder d_model={f} heads={h} Sq={sq} Skv={skv} hidden={u} pre-norm fwd+bwd+SGD, batch {b} '
+                 '(reference transformer.py:95-203; not a BASELINE.json config)')
+        # self-attention: 12 projections over Sq rows + 6 products S^2; cross-attention: q/out projections over Sq rows (6),
+        # k/v projections over Skv rows (6), 6 products Sq x Skv; feed-forward: 6 GEMMs
+        flops = (12 * 2.0 * b * sq * f * f + 6 * 2.0 * b * sq * sq * f
+                 + 6 * 2.0 * b * sq * f * f + 6 * 2.0 * b * skv * f * f + 6 * 2.0 * b * sq * skv * f
+                 + 6 * 2.0 * b * sq * f * u)
+
+        def step_dec():
+            layer(x, kv)
+            layer(dy, backprop=True, optimizer_=sgd)
+        return label, b, flops, step_dec
     else:
         raise ValueError(name)
 
@@ -193,8 +218,8 @@ def main():
     import np_modeling_amd as npm
     from np_modeling_amd import device as D
 
-    for name in NAMES:
-        if args.only and args.only != name:
+    for name in NAMES + EXTRA:
+        if (args.only and args.only != name) or (not args.only and name in EXTRA):
             continue
         r = run_config(name, npm, D, args.steps, args.min_seconds, args.kernels, args.conv_batch)
         for k, row in (r.get('kernels') or {}).items():
