@@ -475,7 +475,12 @@ mha_bwd_kernel(const MhaArgs p) {
     auto load_vfrag = [&](int kb) {
         const int row = kb * 128 + kvl;
 #pragma unroll
-        for (int g = 0; g < NG; ++g) vf[g] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 8 * g + 4 * half) * 4) : OOB);
+        for (int g = 0; g < NG; ++g) {
+            vf[g] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 8 * g + 4 * half) * 4) : OOB);
+            // the 1 / sqrt(Dk) of dS = scale P (dP - delta) rides the operand of the dP product (and delta, mha_delta_kernel):
+            // NG multiplies per key block instead of 16 per tile
+            vf[g].x *= p.scale; vf[g].y *= p.scale; vf[g].z *= p.scale; vf[g].w *= p.scale;
+        }
     };
     constexpr int SEAM_STORES = VEC == 4 ? 32 + 4 : 0;   // D = 128: 32 dK/dV stores + the last tile's 4 dQ stores stay in flight
     issue_kblock(0);
@@ -484,8 +489,11 @@ mha_bwd_kernel(const MhaArgs p) {
     issue_half(0, 0, 1);
     int it = 0;                                          // tiles done so far: stage parity
     // Row terms of the next tile (one query per lane), fetched one tile ahead -- across the seams too
+    // (put into the wave's 256 bytes of LDS at the END of the tile before -- here for the first one -- so that a
+    // tile starts with the reads alone: "query on the lane" becomes "query in the registers")
     float lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, l32 * 4, 0, 0));
     float dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, l32 * 4, 0, 0));
+    if (half == 0) { xs[l32] = lse_n * LOG2E; xs[32 + l32] = dlt_n; }
 
     if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int kb = 0; kb < nkb; ++kb) {
@@ -517,7 +525,6 @@ mha_bwd_kernel(const MhaArgs p) {
             const int q0 = 32 * qt;
             // Row terms, from "query on the lane" to "query in the registers", through 256 bytes of LDS private to the
             // wave; read back at once (a read inside a later phase would wait behind that phase's operand prefetch).
-            if (half == 0) { xs[l32] = lse_n * LOG2E; xs[32 + l32] = dlt_n; }    // (the multiply HERE: at the load it would wait for it)
             float Lr[16], Dr[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -603,7 +610,7 @@ mha_bwd_kernel(const MhaArgs p) {
                 float pr = fast_exp2(fmaf(S[r], c, -Lr[r]));
                 if (MASK && mk[r] == 0) pr = 0.f;      // (a key or query beyond the end reads 0 too: its P is never used)
                 P[r] = pr;
-                dS[r] = pr * (dP[r] - Dr[r]) * p.scale;
+                dS[r] = pr * (dP[r] - Dr[r]);                 // dP and delta carry the 1 / sqrt(Dk) already
                 sDS[ebs[(r >> 2) & 1][r & 3] + 8 * (r >> 2) * 128] = dS[r];
             }
             STAMP(2);
@@ -676,6 +683,9 @@ mha_bwd_kernel(const MhaArgs p) {
                 for (int t = 0; t < DT; ++t) dK[t] = MFMA(ea[r & 1][t], dS[r], dK[t]);
                 FENCE();
             }
+            // the next tile's row terms (requested at the top of this one) go to LDS now: the reads at the top of this
+            // tile are long done, and the next tile starts without a write -> read round trip
+            if (half == 0) { xs[l32] = lse_n * LOG2E; xs[32 + l32] = dlt_n; }
             in_flight = 4;
             ++it;
             STAMP(6);
@@ -714,10 +724,10 @@ mha_bwd_kernel(const MhaArgs p) {
 long long *g_attn_trace = nullptr;
 int g_attn_stagger = 1;
 
-// delta[b, h, s] = sum_d dO[b, s, h, d] * O[b, s, h, d]: half a wavefront (32 lanes x float4) per (b, s, h) row.
+// delta[b, h, s] = scale * sum_d dO[b, s, h, d] * O[b, s, h, d]: half a wavefront (32 lanes x float4) per (b, s, h) row.
 __global__ void __launch_bounds__(256)
 mha_delta_kernel(const float *__restrict__ dctx, long dctx_pitch, const float *__restrict__ ctx, long ctx_pitch,
-                 float *__restrict__ delta, long batch, long seq, int heads, int dim) {
+                 float *__restrict__ delta, long batch, long seq, int heads, int dim, float scale) {
     const long rows = batch * seq * heads;
     const int sub = threadIdx.x & 31;
     const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
@@ -734,7 +744,7 @@ mha_delta_kernel(const float *__restrict__ dctx, long dctx_pitch, const float *_
     for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
     if (sub == 0) {
         const long s_ = bs % seq, b_ = bs / seq;
-        delta[(b_ * heads + h) * seq + s_] = acc;
+        delta[(b_ * heads + h) * seq + s_] = acc * scale;
     }
 }
 
@@ -864,7 +874,7 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
     a.delta = (float *)ws.ptr;
     NPM_ARG((rows * 32 + 255) / 256 < (1L << 31));
     hipLaunchKernelGGL(mha_delta_kernel, dim3((int)((rows * 32 + 255) / 256)), dim3(256), 0, s, a.dctx, a.dctx_pitch,
-                       (const float *)a.ctx, a.ctx_pitch, a.delta, (long)a.batch, (long)a.seq_q, a.heads, c->head_dim);
+                       (const float *)a.ctx, a.ctx_pitch, a.delta, (long)a.batch, (long)a.seq_q, a.heads, c->head_dim, a.scale);
     NPM_CHECK_LAUNCH();
     npm::note_math(NPM_MATH_F32);
     switch (c->head_dim) {
