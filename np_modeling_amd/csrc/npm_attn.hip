@@ -721,8 +721,289 @@ mha_bwd_kernel(const MhaArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, head size 128, saved scores: EIGHT wavefronts per block on v_mfma_f32_16x16x4_f32.
+// The 32 x 32 kernel above keeps 32 keys per wave and with them the whole register file: one wave per SIMD, and every
+// instruction that is not an MFMA (operand reads, waits, the exp / dS arithmetic, address bookkeeping) is time the
+// matrix pipe stands still -- 75 % of the cycles of a tile were MFMA cycles (profiles/r03_attn_core.log).  Here a wave
+// owns 16 keys: dK^T and dV^T accumulators (128 x 16 each), the V fragment and the S / P / dP / dS tiles of 32 queries
+// fit 256 registers, two waves share a SIMD and fill each other's gaps.  Same LDS budget (K block, two Q / dO stages,
+// the dS tile), same products, same order of summation over the key blocks for dQ (bitwise reproducible).
+//
+// 16 x 16 x 4 operand layout: lane l supplies A[i = l & 15][k = l >> 4] and B[k = l >> 4][j = l & 15]; the result has
+// its column j = l & 15 on the lane and rows 4 (l >> 4) + r in registers r = 0..3.  With kk = l >> 4:
+//   dP[q, kv]   = dO[q, d] V^T[d, kv]   A = row q = 16 t + l16 of the dO tile, 16 bytes at d = 16 c + 4 kk (one read per
+//                                        4 MFMAs), B = the V fragment in registers (same d order)
+//   dV^T[d, kv] += dO^T[d, q] P[q, kv]  A = 16 bytes of row q = 16 t + 4 kk + r at d = 4 l16 (+ 64): element e is row l16
+//                                        of d-tile e (+ 4); B = P[t][r]: register for register the result of the exp
+//   dK^T[d, kv] += Q^T[d, q] dS[q, kv]  likewise with the Q tile and dS
+//   dQ^T[d, q]  += K^T[d, kv] dS^T[kv, q] over the 128 keys of the block, wave w taking d = 16 w .. 16 w + 15:
+//                                        A = K[kv = 16 c + 4 kk + s][d] (4-byte reads of the K block), B = row q of the dS
+//                                        tile in LDS, 16 bytes at kv = 16 c + 4 kk
+// ---------------------------------------------------------------------------------------------------------------
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+__global__ void __launch_bounds__(512, 1)
+mha_bwd16_kernel(const MhaArgs p) {
+    constexpr int D = 128;
+    using T = Tile<D>;
+    constexpr int QTILE = 32 * D, KBLK = 128 * D, ROWS16 = 16 * D;         // floats
+    // one __shared__ object, pieces issued from inline assembly (see mha_bwd_kernel)
+    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + 32 * 128 + 8 * 64];
+    float *const sKB = smem, *const sQ = sKB + KBLK, *const sDO = sQ + 2 * QTILE, *const sDS = sDO + 2 * QTILE, *const sRow = sDS + 32 * 128;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0 .. 7
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    float *xs = sRow + wave * 64;
+
+    const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
+    const auto descQ = make_desc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
+    const auto descDO = make_desc(p.dctx + (long)b * p.seq_q * p.dctx_pitch + h * D, ((long)(p.seq_q - 1) * p.dctx_pitch + D) * 4);
+    const auto rsrcDQ = make_rsrc(p.dq + (long)b * p.seq_q * p.dq_pitch + h * D, ((long)(p.seq_q - 1) * p.dq_pitch + D) * 4);
+    const auto rsrcDK = make_rsrc(p.dk + (long)b * p.seq_kv * p.dk_pitch + h * D, ((long)(p.seq_kv - 1) * p.dk_pitch + D) * 4);
+    const auto rsrcDV = make_rsrc(p.dv + (long)b * p.seq_kv * p.dv_pitch + h * D, ((long)(p.seq_kv - 1) * p.dv_pitch + D) * 4);
+    const auto rsrcNone = make_rsrc(p.dq, 0);
+    const auto rsrcL = make_rsrc(p.lse + (long)bh * p.seq_q, (long)p.seq_q * 4);
+    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.seq_q, (long)p.seq_q * 4);
+    const auto rsrcS = make_rsrc(p.scores + (long)bh * p.seq_q * p.seq_kv, (long)p.seq_q * p.seq_kv * 4);
+    const int srow_bytes = p.seq_kv * 4;
+
+    // ---- LDS-DMA: the Q / dO tiles are 16 pieces each (2 per wave), the K block 64 (8 per wave)
+    unsigned vq[2], vdo[2], vkb[8];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        vq[i] = T::src(lane, wave * 2 + i, p.q_pitch);
+        vdo[i] = T::src(lane, wave * 2 + i, p.dctx_pitch);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vkb[i] = T::src(lane, wave * 8 + i, p.k_pitch);
+    const unsigned qstep = (unsigned)(32 * p.q_pitch * 4), dostep = (unsigned)(32 * p.dctx_pitch * 4);
+    const unsigned lds_q = lds_offset(sQ + wave * 2 * 256), lds_do = lds_offset(sDO + wave * 2 * 256), lds_kb = lds_offset(sKB + wave * 8 * 256);
+
+    // ---- LDS addresses (floats): lane-dependent bases, everything else is an immediate
+    int rb[4], vb[4], ws[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        rb[j] = T::chunk(l16, 4 * j + kk);                 // row reads: row 16 t + l16, chunk 4 c + kk; + t * ROWS16 + (c >> 2) * 64
+        vb[j] = T::elem(4 * kk + j, 4 * l16);              // column vectors: row 16 t + 4 kk + r, columns 4 l16 ..; + t * ROWS16 (+ 64)
+        ws[j] = T::elem(4 * kk + j, 16 * wave + l16);      // single elements: row 16 x + 4 kk + r, column 16 wave + l16; + x * ROWS16
+    }
+
+    const float c = p.scale * LOG2E;
+    const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
+    const int kvl = 16 * wave + l16;                                            // this lane's key inside the block
+    // dQ slice of this wave: head dimensions 16 wave + 4 kk + r of query q0 + 16 t + l16
+    const int dq_voff = (int)((l16 * p.dq_pitch + 16 * wave + 4 * kk) * 4);
+    const int dq_sub = 16 * (int)p.dq_pitch * 4;                                // byte step between the two query sub-tiles
+
+    float4 vf[8];                                                               // V[key][16 c + 4 kk + s] * scale
+    int it = 0;
+    dma_group<8>(descK, lds_kb, 0u, vkb);
+    {
+        const int row = kvl;
+#pragma unroll
+        for (int cc = 0; cc < 8; ++cc) {
+            vf[cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
+            vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale;
+        }
+    }
+    dma_group<2>(descQ, lds_q, 0u, vq);
+    dma_group<2>(descDO, lds_do, 0u, vdo);
+    float lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, (lane & 31) * 4, 0, 0));
+    float dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, (lane & 31) * 4, 0, 0));
+    if (lane < 32) { xs[lane] = lse_n * LOG2E; xs[32 + lane] = dlt_n; }
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        const int kvrow = kb * 128 + kvl;
+        const bool kvok = kvrow < p.seq_kv;
+        f32x4 dK[8], dV[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) { dK[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const auto rsrcOld = kb > 0 ? rsrcDQ : rsrcNone;                         // first key block: "old" dQ reads as 0
+        const int svoff = kvok ? (kvrow + 4 * kk * p.seq_kv) * 4 : OOB;          // scores: this lane's key, its 4 kk rows
+        int in_flight = kb > 0 ? 18 : 0;                 // youngest vector-memory operations that may stay outstanding
+
+        for (int qt = 0; qt < nqt; ++qt) {
+            if (in_flight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (in_flight == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const bool seam = qt + 1 == nqt && kb + 1 < nkb;
+            const int nq = qt + 1 < nqt ? qt + 1 : 0;
+            const int cur = it & 1, nxt = cur ^ 1;
+            const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
+            const int q0 = 32 * qt;
+            // row terms of this tile: queries 16 t + 4 kk + r in the registers
+            f32x4 Lr[2], Dr[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const float4 l4 = ld4(xs + 16 * t + 4 * kk), d4 = ld4(xs + 32 + 16 * t + 4 * kk);
+                Lr[t] = f32x4{l4.x, l4.y, l4.z, l4.w};
+                Dr[t] = f32x4{d4.x, d4.y, d4.z, d4.w};
+            }
+            lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, (lane & 31) * 4, 32 * nq * 4, 0));
+            dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, (lane & 31) * 4, 32 * nq * 4, 0));
+            // raw scores of this tile (nontemporal: read once) and the old dQ values (the dQ accumulators start from them)
+            f32x4 S[2], acc[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    S[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, svoff, (q0 + 16 * t + r) * srow_bytes, 2));
+            const int dq_tile = q0 * (int)p.dq_pitch * 4;
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const u32x4_t o = __builtin_amdgcn_raw_buffer_load_b128(rsrcOld, dq_voff, dq_tile + t * dq_sub, 0);
+                acc[t] = f32x4{__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w)};
+            }
+
+            // ---- dP[q, kv] = dO V^T: 8 steps of (2 row reads, 8 MFMAs), reads one step ahead
+            f32x4 dP[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            float4 fa[2][2];
+            fa[0][0] = ld4(tDO + rb[0]);
+            fa[0][1] = ld4(tDO + rb[0] + ROWS16);
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                if (cc + 1 < 8) {
+                    fa[(cc + 1) & 1][0] = ld4(tDO + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
+                    fa[(cc + 1) & 1][1] = ld4(tDO + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + ROWS16);
+                }
+                FENCE();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    dP[t] = MFMA16(fa[cc & 1][t].x, vf[cc].x, dP[t]);
+                    dP[t] = MFMA16(fa[cc & 1][t].y, vf[cc].y, dP[t]);
+                    dP[t] = MFMA16(fa[cc & 1][t].z, vf[cc].z, dP[t]);
+                    dP[t] = MFMA16(fa[cc & 1][t].w, vf[cc].w, dP[t]);
+                }
+                FENCE();
+            }
+            // ---- P = exp(scale S - LSE); dS = P (dP - delta) (both carry the 1 / sqrt(Dk) already), also into LDS
+            f32x4 P[2], dS[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pr = fast_exp2(fmaf(S[t][r], c, -Lr[t][r]));
+                    P[t][r] = pr;
+                    dS[t][r] = pr * (dP[t][r] - Dr[t][r]);
+                    sDS[ws[r] + t * ROWS16] = dS[t][r];
+                }
+            // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (2 vector reads, 8 MFMAs)
+            float4 ea[2][2];
+            ea[0][0] = ld4(tDO + vb[0]);
+            ea[0][1] = ld4(tDO + vb[0] + 64);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int t = st >> 2, r = st & 3;
+                if (st + 1 < 8) {
+                    ea[(st + 1) & 1][0] = ld4(tDO + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16);
+                    ea[(st + 1) & 1][1] = ld4(tDO + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16 + 64);
+                }
+                FENCE();
+                const float4 e0 = ea[st & 1][0], e1 = ea[st & 1][1];
+                dV[0] = MFMA16(e0.x, P[t][r], dV[0]); dV[1] = MFMA16(e0.y, P[t][r], dV[1]);
+                dV[2] = MFMA16(e0.z, P[t][r], dV[2]); dV[3] = MFMA16(e0.w, P[t][r], dV[3]);
+                dV[4] = MFMA16(e1.x, P[t][r], dV[4]); dV[5] = MFMA16(e1.y, P[t][r], dV[5]);
+                dV[6] = MFMA16(e1.z, P[t][r], dV[6]); dV[7] = MFMA16(e1.w, P[t][r], dV[7]);
+                FENCE();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                                      // dS of all eight key groups is in LDS
+            asm volatile("" ::: "memory");
+
+            // ---- dQ^T[d, q] (+)= K^T[d, kv] dS^T[kv, q] over the 128 keys: 8 steps of (4 element reads, 2 row reads, 8 MFMAs)
+            float ak[2][4];
+            float4 da[2][2];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ak[0][s] = sKB[ws[s]];
+            da[0][0] = ld4(sDS + rb[0]);
+            da[0][1] = ld4(sDS + rb[0] + ROWS16);
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                if (cc + 1 < 8) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) ak[(cc + 1) & 1][s] = sKB[ws[s] + (cc + 1) * ROWS16];
+                    da[(cc + 1) & 1][0] = ld4(sDS + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
+                    da[(cc + 1) & 1][1] = ld4(sDS + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + ROWS16);
+                }
+                // the next tile's Q / dO pieces go out here: behind every load this tile still waits for
+                if (cc == 1) dma_group<2>(descQ, lds_q + nxt * QTILE * 4, nq * qstep, vq);
+                if (cc == 5) dma_group<2>(descDO, lds_do + nxt * QTILE * 4, nq * dostep, vdo);
+                FENCE();
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    acc[t] = MFMA16(ak[cc & 1][0], da[cc & 1][t].x, acc[t]);
+                    acc[t] = MFMA16(ak[cc & 1][1], da[cc & 1][t].y, acc[t]);
+                    acc[t] = MFMA16(ak[cc & 1][2], da[cc & 1][t].z, acc[t]);
+                    acc[t] = MFMA16(ak[cc & 1][3], da[cc & 1][t].w, acc[t]);
+                }
+                FENCE();
+            }
+            if (seam) {                                // every wave is done with this K block: request the next one
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dma_group<8>(descK, lds_kb, (unsigned)((kb + 1) * 128 * p.k_pitch * 4), vkb);
+                const int row = (kb + 1) * 128 + kvl;
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) {
+                    vf[cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
+                    vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale;
+                }
+            }
+            // ---- dK^T[d, kv] += Q^T[d, q] dS[q, kv]; the dQ stores ride along
+            ea[0][0] = ld4(tQ + vb[0]);
+            ea[0][1] = ld4(tQ + vb[0] + 64);
+#pragma unroll
+            for (int st = 0; st < 8; ++st) {
+                const int t = st >> 2, r = st & 3;
+                if (st + 1 < 8) {
+                    ea[(st + 1) & 1][0] = ld4(tQ + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16);
+                    ea[(st + 1) & 1][1] = ld4(tQ + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16 + 64);
+                }
+                if (st == 0 || st == 4) {
+                    const int tt = st >> 2;
+                    const u32x4_t v = {__float_as_uint(acc[tt][0]), __float_as_uint(acc[tt][1]), __float_as_uint(acc[tt][2]), __float_as_uint(acc[tt][3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrcDQ, dq_voff, dq_tile + tt * dq_sub, 0);
+                }
+                FENCE();
+                const float4 e0 = ea[st & 1][0], e1 = ea[st & 1][1];
+                dK[0] = MFMA16(e0.x, dS[t][r], dK[0]); dK[1] = MFMA16(e0.y, dS[t][r], dK[1]);
+                dK[2] = MFMA16(e0.z, dS[t][r], dK[2]); dK[3] = MFMA16(e0.w, dS[t][r], dK[3]);
+                dK[4] = MFMA16(e1.x, dS[t][r], dK[4]); dK[5] = MFMA16(e1.y, dS[t][r], dK[5]);
+                dK[6] = MFMA16(e1.z, dS[t][r], dK[6]); dK[7] = MFMA16(e1.w, dS[t][r], dK[7]);
+                FENCE();
+            }
+            // the next tile's row terms (requested at the top of this one) go to LDS now
+            if (lane < 32) { xs[lane] = lse_n * LOG2E; xs[32 + lane] = dlt_n; }
+            in_flight = 2;
+            ++it;
+            FENCE();
+        }
+        // this block's dK and dV rows: lane = key; registers r of tiles 4 x + 0..3 are 4 adjacent head dimensions
+        // 64 x + 16 kk + 4 r + e
+#pragma unroll
+        for (int x = 0; x < 2; ++x)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int d0 = 64 * x + 16 * kk + 4 * r;
+                const int offk = kvok ? (int)((kvrow * p.dk_pitch + d0) * 4) : OOB, offv = kvok ? (int)((kvrow * p.dv_pitch + d0) * 4) : OOB;
+                buf_store4(rsrcDK, offk, dK[4 * x][r], dK[4 * x + 1][r], dK[4 * x + 2][r], dK[4 * x + 3][r]);
+                buf_store4(rsrcDV, offv, dV[4 * x][r], dV[4 * x + 1][r], dV[4 * x + 2][r], dV[4 * x + 3][r]);
+            }
+    }
+}
+
 long long *g_attn_trace = nullptr;
 int g_attn_stagger = 1;
+int g_attn_bwd16 = 1;          // NPM_TUNE_ATTN_BWD16: head size 128 with saved scores on the 8-wave 16 x 16 x 4 kernel
 
 // delta[b, h, s] = scale * sum_d dO[b, s, h, d] * O[b, s, h, d]: half a wavefront (32 lanes x float4) per (b, s, h) row.
 __global__ void __launch_bounds__(256)
@@ -781,7 +1062,8 @@ int launch_bwd(const MhaArgs &a, hipStream_t s) {
     // Saved scores already CARRY the mask (the forward stored -inf at every masked position, so P = exp2(-inf) = 0
     // there): the backward needs the mask bytes only when it recomputes q.k.  One instance less per head size -- the
     // one whose 16 extra byte loads per tile did not fit the register file at D = 128.
-    if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
+    if (saved && D == 128 && g_attn_bwd16 && !a.trace) hipLaunchKernelGGL(mha_bwd16_kernel, dim3(grid), dim3(512), 0, s, a);
+    else if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
     else if (mask) launch_bwd_instance<D, true, false>(a, grid, s);
     else launch_bwd_instance<D, false, false>(a, grid, s);
     NPM_CHECK_LAUNCH();
@@ -834,6 +1116,7 @@ int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
 
 extern "C" int npm_debug_attn_trace(long long *buf) { g_attn_trace = buf; return NPM_OK; }
 extern "C" int npm_attn_set_stagger(int units) { g_attn_stagger = units < 0 ? 0 : units; return NPM_OK; }
+extern "C" int npm_attn_set_bwd16(int on) { g_attn_bwd16 = on != 0; return NPM_OK; }
 
 extern "C" int npm_mha_core_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
 

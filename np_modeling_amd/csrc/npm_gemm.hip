@@ -412,6 +412,7 @@ extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
 extern "C" int npm_conv_set_wave_prio(int bits);
 extern "C" int npm_conv_set_math(int mode);
 extern "C" int npm_conv_set_wgrad_fused(int mode);
+extern "C" int npm_attn_set_bwd16(int on);
 extern "C" int npm_attn_set_stagger(int units);
 
 extern "C" int npm_set_math(int mode) { return npm_set_tuning(NPM_TUNE_GEMM_MATH, mode); }
@@ -436,6 +437,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         case NPM_TUNE_ATTN_STAGGER: return npm_attn_set_stagger(value);
+        case NPM_TUNE_ATTN_BWD16: return npm_attn_set_bwd16(value);
         case NPM_TUNE_STREAM_NT: npm::set_stream_nt(value); return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }

@@ -21,6 +21,7 @@ ap.add_argument('--d', type=int, default=128)
 ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--save-scores', action='store_true')
 ap.add_argument('--tune', default='')
+ap.add_argument('--mask', default='', choices=['', 'causal', 'random'], help='attention mask: causal [1,1,S,S] (broadcast over batch and head) or random per (b, h)')
 a = ap.parse_args()
 for item in filter(None, a.tune.split(',')):
     knob, value = item.split('=')
@@ -35,14 +36,23 @@ dqkv = D.empty([b, s, 3, h, d])
 dq, dk, dv = dqkv, dqkv.flat_view(f, [dqkv.size - f]), dqkv.flat_view(2 * f, [dqkv.size - 2 * f])
 dims = (b, h, s, s, d)
 scale = 1.0 / np.sqrt(d)
+mask = None
+if a.mask == 'causal':
+    mask = D.AttnMask(np.tril(np.ones([s, s], dtype=bool))[None, None], b, h, s, s)
+elif a.mask == 'random':
+    m = rng.random([b, h, s, s]) < 0.7
+    m[..., 0] = True
+    mask = D.AttnMask(m, b, h, s, s)
+    del m
+print(f'B {b} H {h} S {s} D {d}, mask {a.mask or "none"}, scores {"saved" if a.save_scores else "recomputed"}')
 for name in ('fwd', 'bwd'):
     for rep in range(a.reps + 1):
         with D.KernelTimer() as t:
             if name == 'fwd':
-                ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, save_scores=a.save_scores)
+                ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, mask=mask, save_scores=a.save_scores)
             else:
                 D.mha_core_bwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), ctx, lse, dctx, Mat(dq, 3 * f), Mat(dk, 3 * f),
-                               Mat(dv, 3 * f), dims, scale, scores=scores)
+                               Mat(dv, 3 * f), dims, scale, mask=mask, scores=scores)
         rec = list(t.summary().values())[0]
         if rep:
             print(f'mha_core_{name}: {rec["ms"]:.3f} ms  {rec["flops"] / rec["ms"] / 1e9:.1f} TF  '

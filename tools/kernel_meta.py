@@ -47,8 +47,14 @@ def demangle(names):
 def kernel_metadata(obj):
     """{demangled kernel name: {field: int}} for every kernel of a built host object."""
     with tempfile.TemporaryDirectory() as tmp:
-        notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', device_image(obj, tmp)], check=True,
+        try:
+            image = device_image(obj, tmp)
+        except RuntimeError:
+            return {}                     # an object without device code (npm_runtime.o)
+        notes = subprocess.run([os.path.join(LLVM, 'llvm-readelf'), '--notes', image], check=True,
                                capture_output=True, text=True).stdout
+    if 'amdhsa.kernels' not in notes:
+        return {}
     import yaml
     doc = yaml.safe_load(notes[notes.index('---'):notes.rindex('...')])
     kernels = {k['.name']: k for k in doc['amdhsa.kernels']}
