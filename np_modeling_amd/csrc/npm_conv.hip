@@ -405,8 +405,8 @@ conv_wgrad_glds_kernel(const ConvArgs p) {
 // dw = gather(x)^T g with g = where(pre >= 0, dy, 0) (activations.py:19), db = sum over pixels of g (conv.py:55) and
 // g itself written out once for the grad_x convolution.  The standalone ReLU-backward pass (12 B per element of
 // [N, H, W, C1]: 3.7 of the 48 ms of config C3) is gone: the DENSE operand of this GEMM is staged through registers
-// (global -> registers -> mask -> LDS) instead of by LDS-DMA, which is where the mask is applied; the blocks of tile
-// row 0 also store g and sum its columns.  The gathered operand keeps the LDS-DMA path (from inline assembly,
+// (global -> registers -> mask -> LDS) instead of by LDS-DMA, which is where the mask is applied; the tile rows take
+// turns storing g and summing its columns.  The gathered operand keeps the LDS-DMA path (from inline assembly,
 // npm_mfma_tile.h), with the image-border test hoisted out of the lanes: a K tile is 16 consecutive pixels, and
 // unless that run touches a border (or wraps to the next image row) every tap of every lane is in range -- a scalar
 // test per tile; only border tiles (15 % at 224 x 224) compute per-lane offsets.
@@ -427,7 +427,7 @@ __device__ __forceinline__ float4 relu_mask4(const u32x4 &pre, const u32x4 &dy) 
 struct WgradArgs {
     const float *X, *DY, *PRE;
     float *G;            // optional: the masked dy, [pixels, N]
-    float *colpart;      // optional: [splits][N] column sums of g per split
+    float *colpart;      // optional: [splits][tiles_m][N] column sums of the g tiles each block produced
     float *out;          // slabs [splits][M][N] (or dw itself when splits == 1)
     int H, W, C, ks, pad;
     int M, N, K;
@@ -455,7 +455,11 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
     const int nkt = (kend - kbeg) / GK;
-    const bool first_row = tm == 0;                    // these blocks write g and sum its columns
+    // g (and its column sums) is produced once per (split, column tile): the tile rows take turns, K tile kt belongs to
+    // tile row kt % tiles_m -- all blocks of the launch are resident at once and end together, so the extra stores and
+    // adds must not all fall on the blocks of one tile row.
+    int turn = tm;                                     // K tiles until this block's next turn
+    bool stored = false;                               // the previous staging issued g stores
 
     // ---- gathered operand: descriptor over pixels [kbeg - halo, kend + halo)
     const int halo = p.pad * p.W + p.pad;
@@ -485,7 +489,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
     const auto rsrcDY = __builtin_amdgcn_make_buffer_rsrc((void *)(p.DY + (long)kbeg * p.N), 0, (int)(rows_left * p.N * 4), 0x00020000);
     const auto rsrcPRE = __builtin_amdgcn_make_buffer_rsrc((void *)(p.PRE + (long)kbeg * p.N), 0, (int)(rows_left * p.N * 4), 0x00020000);
     const auto rsrcG = __builtin_amdgcn_make_buffer_rsrc((void *)((p.G ? p.G : p.out) + (long)kbeg * p.N), 0,
-                                                         (p.G && first_row) ? (int)(rows_left * p.N * 4) : 0, 0x00020000);
+                                                         p.G ? (int)(rows_left * p.N * 4) : 0, 0x00020000);
     const int vb0 = ncol < p.N ? ((tid >> 5) * p.N + ncol) * 4 : OOB;
     const int vb1 = ncol < p.N ? (((tid >> 5) + 8) * p.N + ncol) * 4 : OOB;
     float *const sBw = smem + A_TILE + (tid >> 5) * BN + 4 * (tid & 31);      // + stage * STAGE (+ 8 BN for the second row)
@@ -533,7 +537,9 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
         const float4 g0 = relu_mask4(q0, d0), g1 = relu_mask4(q1, d1);                                             \
         *reinterpret_cast<float4 *>(sBw + (STG) * STAGE) = g0;                                                     \
         *reinterpret_cast<float4 *>(sBw + (STG) * STAGE + 8 * BN) = g1;                                            \
-        if (first_row) {                                                                                           \
+        stored = turn == 0;                                                                                        \
+        turn = turn == 0 ? p.tiles_m - 1 : turn - 1;                                                               \
+        if (stored) {                                                                                              \
             const u32x4 s0 = {__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)};  \
             const u32x4 s1 = {__float_as_uint(g1.x), __float_as_uint(g1.y), __float_as_uint(g1.z), __float_as_uint(g1.w)};  \
             __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcG, vb0, (KT) * tile_bytes, 0);                          \
@@ -549,7 +555,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
         /* tile KT is in LDS for every wave (the DMA pieces: vmcnt; the masked rows: lgkmcnt); the other stage is   \
            free.  The g stores of the tile before are this wave's youngest vector-memory operations: they stay in  \
            flight. */                                                                                              \
-        if (first_row) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                            \
+        if (stored) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
         __builtin_amdgcn_s_barrier();                                                                              \
@@ -600,7 +606,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
                                                       (wm * 32 * WR + i * 32 + (r & 3) + 8 * (r >> 2)) * p.N * 4, 0);
     }
     // ---- column sums of g over this split's pixels: the 8 k-row groups of the block through LDS, fixed order
-    if (first_row && p.colpart) {
+    if (p.colpart) {
         __syncthreads();                                // every wave is done with the operand stages
         *reinterpret_cast<float4 *>(smem + (tid >> 5) * BN + 4 * (tid & 31)) = colacc;
         __syncthreads();
@@ -608,7 +614,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
             float total = 0.f;
 #pragma unroll
             for (int r = 0; r < 8; ++r) total += smem[r * BN + tid];
-            if (n0 + tid < p.N) p.colpart[(long)split * p.N + n0 + tid] = total;
+            if (n0 + tid < p.N) p.colpart[((long)split * p.tiles_m + tm) * p.N + n0 + tid] = total;
         }
     }
 }
@@ -827,7 +833,7 @@ int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, flo
                           tiles * splits < (1L << 31);
         if (fits) {
             npm::Scratch ws, parts;
-            int rc = parts.alloc(sizeof(float) * (size_t)splits * c_out);
+            int rc = parts.alloc(sizeof(float) * (size_t)splits * a.tiles_m * c_out);
             if (rc) return rc;
             a.colpart = (float *)parts.ptr;
             a.slab = (long)m * c_out;
@@ -852,7 +858,7 @@ int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, flo
                 rc = launch_splitk_reduce(r, s);
                 if (rc) return rc;
             }
-            return npm_colsum(a.colpart, db, splits, c_out, c_out);       // fixed order over the splits
+            return npm_colsum(a.colpart, db, (int64_t)splits * a.tiles_m, c_out, c_out);       // fixed order over the partial rows
         }
     }
     int rc = npm_relu_bwd_colsum(pre, dy, g, db, pixels, c_out);

@@ -103,6 +103,16 @@ def main():
     busy_a, rate_a = measure(path, lambda: D.add(big[0], big[1], out=big[2]), D, args.seconds)
     tbps_a = rate_a * 12.0 * (1 << 28) / 1e12
     per_tbps = busy_a / tbps_a
+    if busy_a < 1.0:
+        print(f'calibration A (add, 3 x 1 GiB, HBM): {tbps_a:.2f} TB/s of algorithmic traffic at mem_busy {busy_a:.1f} %')
+        print('mem_busy_percent stays at 0 under a kernel that streams from HBM at that rate: the SMU figure is not wired up for '
+              'this (virtualised) device, and rocprofv3 exposes no memory-controller or Infinity-Cache counters on gfx950 '
+              '(TCC / TCP / SQ / SPI / TA / TD / CPC / GRBM only; TCC_EA0_RDREQ_DRAM counts the same requests as TCC_EA0_RDREQ: '
+              'profiles/*_pmc_tcc_ffn_dw.log).  HBM-side traffic cannot be separated from Infinity-Cache service here.')
+        if args.json:
+            with open(args.json, 'w') as f:
+                json.dump({'usable': False, 'hbm_stream_tbps': tbps_a, 'hbm_stream_busy_pct': busy_a, 'source': path}, f, indent=1)
+        return 0
     print(f'calibration A (add, 3 x 1 GiB, HBM): {tbps_a:.2f} TB/s of algorithmic traffic at mem_busy {busy_a:.1f} % -> {per_tbps:.2f} % per TB/s')
     del big
     small = [D.empty([1 << 22]) for _ in range(3)]          # 16 MiB each: Infinity-Cache resident
