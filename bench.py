@@ -153,7 +153,10 @@ def load_pmc_traffic(args):
         return None, None
     with open(path) as f:
         data = json.load(f)
-    return data['gemm_family_bytes_per_launch'], 'profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes; includes Infinity-Cache hits'
+    return data['gemm_family_bytes_per_launch'], ('profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes: requests that leave the '
+                                                 'L2s (fabric side), Infinity-Cache hits included.  An HBM-side figure cannot be taken on this pool: rocprofv3 exposes no '
+                                                 'memory-controller / Infinity-Cache counters on gfx950 and the SMU mem_busy figure reads 0 (profiles/r03_hbm_side.log, '
+                                                 'profiles/r03_pmc_tcc_ffn_dw.log)')
 
 
 def main():
