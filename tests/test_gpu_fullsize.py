@@ -153,7 +153,9 @@ def test_encoder_full_size_fused_equals_unfused(npm):
         if k[1] == '_bk':      # rounding noise around an exact zero in both compositions (see the additivity test)
             assert np.abs(g1[k]).max() < 1e-4 * bq_scale and np.abs(g2[k]).max() < 1e-4 * bq_scale
             continue
-        assert_close(g1[k], g2[k], tol=1e-5, what=str(k[:2]))
+        # two fp32 computations with different summation orders over K = 32768 rows, EACH within 1e-5 of the exact value
+        # (tests/test_gpu_parity.py: the worst parameter gradient, dwq, sits at 6e-6): they may differ by the sum
+        assert_close(g1[k], g2[k], tol=2e-5, what=str(k[:2]))
 
 
 def test_dense_c2_checksum(npm, exact_modes):
