@@ -224,7 +224,10 @@ mha_fwd_kernel(const MhaArgs p) {
     float m = -INFINITY, l = 0.f;
     const float c = p.scale * LOG2E;
     const int nt = (p.seq_kv + 31) / 32;
-    const unsigned char *mrow = MASK ? p.mask + b * p.mask_sb + h * p.mask_sh + (long)qrow * p.mask_sq : nullptr;
+    // mask bytes of this (b, h) behind a descriptor: lane part (its query row, its 4 half keys) in one register, the tile's
+    // first key in the scalar offset, the key inside the tile in the immediate; a key or query beyond the end reads 0 = masked
+    const auto rsrcM = make_rsrc(MASK ? p.mask + b * p.mask_sb + h * p.mask_sh : nullptr, MASK ? (long)(p.seq_q - 1) * p.mask_sq + p.seq_kv : 0);
+    const int mvoff = qok ? (int)(qrow * p.mask_sq + 4 * half) : OOB;
     // Saved scores of this (b, h): [seq_q][seq_kv] behind one descriptor.  A lane's part of the address (its query row,
     // its 4 half keys) is ONE register, the tile's first key a scalar offset, the register group an immediate: a full
     // tile is four bare buffer_store_dwordx4, rows beyond seq_q carry an out-of-range offset.
@@ -247,6 +250,11 @@ mha_fwd_kernel(const MhaArgs p) {
         STAMP(0);
         if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
         const float *sK = smem + (t & 1) * TILE, *sV = smem + (2 + (t & 1)) * TILE;
+        unsigned char mk[16];
+        if (MASK) {                                     // requested now, used behind the 64 MFMAs of the score product
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mk[r] = __builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff + (r & 3) + 8 * (r >> 2), 32 * t, 0);
+        }
 
         // ---- S^T[kv, q] = K Q^T: NG steps of (1 row read, 4 MFMAs), every read one step ahead of its use
         f32x16 S;
@@ -272,12 +280,10 @@ mha_fwd_kernel(const MhaArgs p) {
             for (int r = 0; r < 16; ++r)
                 if (kv0 + (r & 3) + 8 * (r >> 2) >= p.seq_kv) S[r] = -INFINITY;
         }
-        if (MASK && qok) {
+        if (MASK) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kv = kv0 + (r & 3) + 8 * (r >> 2);
-                if (kv < p.seq_kv && mrow[kv] == 0) S[r] = -INFINITY;
-            }
+            for (int r = 0; r < 16; ++r)
+                if (mk[r] == 0) S[r] = -INFINITY;
         }
         if (SAVE) {
             const int stile = 32 * t * 4;                                     // scalar: byte offset of the tile's first key
