@@ -134,6 +134,35 @@ def test_core_vs_oracle(npm, b, h, sq, skv, d):
         assert_close(own[name], want, tol=3e-6, what=name)
 
 
+@pytest.mark.parametrize('b,h,sq,skv', [(1, 1, 1, 1), (2, 3, 32, 32), (2, 2, 33, 47), (1, 2, 100, 257), (1, 3, 200, 130),
+                                         (3, 1, 31, 300), (1, 1, 130, 5), (1, 2, 512, 512), (2, 1, 17, 128), (1, 1, 64, 129)])
+@pytest.mark.parametrize('bwd16', [1, 0])
+def test_core_saved_scores_head_128(npm, b, h, sq, skv, bwd16):
+    """Head size 128 with saved scores -- the default path of C4 / C5 -- through ragged lengths: the backward is the
+    8-wave kernel on v_mfma_f32_16x16x4_f32 (mha_bwd16_kernel: 16 keys per wave, two waves per SIMD; NPM_TUNE_ATTN_BWD16
+    = 1, default) or the 4-wave 32x32x2 kernel (= 0); both against the oracle, and the saved scores themselves."""
+    from np_modeling_amd import _C
+    d = 128
+    rng = np.random.default_rng(b * 1000 + sq * 7 + skv)
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k = rng.standard_normal([b, skv, h, d]).astype(np.float32)
+    v = rng.standard_normal([b, skv, h, d]).astype(np.float32)
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    q64, k64, v64, d64 = (x.astype(np.float64) for x in (q, k, v, dctx))
+    ctx, lse, probs = O.attention_core_fwd(q64, k64, v64, scale)
+    dq, dk, dv = O.attention_core_bwd(q64, k64, v64, probs, d64, scale)
+    _C.check(_C.lib().npm_set_tuning(14, bwd16), 'npm_set_tuning')
+    try:
+        got = _run_core(npm, q, k, v, scale, dctx=dctx, save=True)
+    finally:
+        _C.check(_C.lib().npm_set_tuning(14, 1), 'npm_set_tuning')
+    assert_close(got['ctx'], ctx, tol=2e-6)
+    assert_close(got['scores'], np.einsum('bqhd,bkhd->bhqk', q64, k64), tol=2e-6)
+    for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+        assert_close(got[name], want, tol=3e-6, what=f'{name} bwd16={bwd16}')
+
+
 @pytest.mark.parametrize('b,h,s,d', [(2, 4, 96, 16), (1, 8, 160, 128), (2, 2, 64, 64)])
 def test_core_packed_operands_and_saved_scores(npm, b, h, s, d):
     """q/k/v (and dq/dk/dv) as thirds of one [B, S, 3, H, D] buffer (row pitch 3 H D), and the variant that keeps
