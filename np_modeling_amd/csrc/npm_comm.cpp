@@ -240,7 +240,14 @@ int npm_comm_barrier(void) {
     HIPC(hipStreamSynchronize(g.compute));
     HIPC(hipMemsetAsync(g.scalar, 0, 8, g.stream));
     NCCLC(ncclAllReduce(g.scalar, g.scalar, 1, ncclFloat64, ncclSum, g.comm, g.stream));
-    HIPC(hipStreamSynchronize(g.stream));
+    // Poll with short sleeps instead of hipStreamSynchronize: a rank may wait here for a long time (bench.py: the other
+    // ranks wait while rank 0 times the CPU baseline on the host cores) and must not spin on a core meanwhile.
+    for (long polls = 0;; ++polls) {
+        const hipError_t q = hipStreamQuery(g.stream);
+        if (q == hipSuccess) break;
+        if (q != hipErrorNotReady) return fail((int)q, "npm_comm_barrier: hipStreamQuery -> %s", hipGetErrorString(q));
+        if (polls > 4000) usleep(200);                    // the first millisecond or so spins: a timed region ends in this call
+    }
     return 0;
 }
 
