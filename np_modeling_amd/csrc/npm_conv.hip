@@ -241,6 +241,11 @@ conv_fwd_glds_kernel(const ConvArgs p) {
     // this wave's A pieces: rows 16 j + (lane >> 2), source chunk (lane & 3) ^ swizzle(row)
     int rowv[A_PIECES], ph[A_PIECES], pw[A_PIECES];
     unsigned vbase[A_PIECES];
+    // A piece is 16 consecutive pixels.  Unless that run touches an image border (or wraps to the next image row, or
+    // leaves the tensor) every lane's tap is in range, and which taps those are is known per piece: bit t of hmask /
+    // wmask = "row offset t - pad / column offset t - pad keeps all 16 pixels inside".  The per-lane validity test is
+    // then needed for the border pieces only (7 % of the (piece, tap) pairs at 224 x 224) -- a scalar test per piece.
+    unsigned hmask[A_PIECES], wmask[A_PIECES];
 #pragma unroll
     for (int i = 0; i < A_PIECES; ++i) {
         const int row = 16 * (A_PIECES * wave + i) + (lane >> 2);
@@ -250,6 +255,18 @@ conv_fwd_glds_kernel(const ConvArgs p) {
         pw[i] = m % p.W;
         ph[i] = (m / p.W) % p.H;
         vbase[i] = (unsigned)((row * p.C + c * 4) * 4);
+        const int mp = m0 + 16 * (A_PIECES * wave + i);         // first pixel of the piece (wave-uniform)
+        const int pwf = mp % p.W, phf = (mp / p.W) % p.H;
+        unsigned hm = 0, wm = 0;
+        if (p.ks <= 31 && pwf + 15 < p.W && mp + 15 < p.M) {
+            for (int t = 0; t < p.ks; ++t) {
+                const int d = t - p.pad;
+                hm |= (unsigned)((unsigned)(phf + d) < (unsigned)p.H) << t;
+                wm |= (unsigned)(pwf + d >= 0 && pwf + 15 + d < p.W) << t;
+            }
+        }
+        hmask[i] = __builtin_amdgcn_readfirstlane(hm);
+        wmask[i] = __builtin_amdgcn_readfirstlane(wm);
     }
     // B pieces ([16 k][TN] rows of TN floats): a 1 KiB piece covers 1024 / (4 TN) k rows
     constexpr int ROWS_PER_PIECE = 256 / TN, LANES_PER_ROW = TN / 4;
@@ -271,9 +288,14 @@ conv_fwd_glds_kernel(const ConvArgs p) {
         const int di = ti - p.pad, dj = tj - p.pad;                                                          \
         const unsigned soff = (unsigned)(((halo + di * p.W + dj) * p.C + c0) * 4);                           \
         _Pragma("unroll") for (int i = 0; i < A_PIECES; ++i) {                                               \
-            const bool ok = rowv[i] < p.M && (unsigned)(ph[i] + di) < (unsigned)p.H &&                       \
-                            (unsigned)(pw[i] + dj) < (unsigned)p.W;                                          \
-            lds_dma16(rsrcA, sa + 256 * i, ok ? vbase[i] : (unsigned)OOB_OFFSET, soff);                      \
+            if ((hmask[i] >> ti) & (wmask[i] >> tj) & 1u) {                                                  \
+                lds_dma16(rsrcA, sa + 256 * i, vbase[i], soff);                                              \
+            } else {                                                                                         \
+                const bool ok = rowv[i] < p.M && (unsigned)(ph[i] + di) < (unsigned)p.H &&                   \
+                                (unsigned)(pw[i] + dj) < (unsigned)p.W;                                      \
+                asm volatile("; border piece" ::: "memory");                                                 \
+                lds_dma16(rsrcA, sa + 256 * i, ok ? vbase[i] : (unsigned)OOB_OFFSET, soff);                  \
+            }                                                                                                \
         }                                                                                                    \
         const unsigned kb = (unsigned)((KT) * GK * p.N * 4);                                                 \
         _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i)                                                 \
