@@ -250,29 +250,48 @@ sgemm_glds_kernel(const GemmArgs p) {
     if (nkt > 0) issue(0, 0);
     if (NSTAGE == 3 && nkt > 1) issue(1, 1);
     prio_low(p.e.prio & 1);
-    int stage = 0;
-    for (int kt = 0; kt < nkt; ++kt) {
-        // tile kt has landed (every wave's pieces) and everybody is done reading the stage about to be refilled
-        if (NSTAGE == 3) {
+    // one K tile out of stage STG: tile KT has landed (every wave's pieces) and everybody is done reading the stage about
+    // to be refilled; the next tile goes out, then the 32 MFMAs
+#define NPM_GEMM_TILE(KT, STG)                                                                                       \
+    do {                                                                                                             \
+        if (!(p.ablate & 4)) dma_barrier();                                                                          \
+        if (p.trace && (KT) == 0) t_first = __builtin_amdgcn_s_memtime();                                            \
+        if ((KT) + 1 < nkt && !(p.ablate & 1)) issue((KT) + 1, (STG) ^ 1);                                           \
+        const float *sA = smem + (STG) * STAGE;                                                                      \
+        const float *sB = sA + A_TILE;                                                                               \
+        if (KSUM && do_ksum) {                                                                                       \
+            const float *st = (KSUM == 1 ? sB : sA) + (tid & 127);          /* both tiles are [16 k][128] here */    \
+            for (int r = ks_row0; r < GK; r += 2 * ks_share) ks_acc += st[r * 128];                                  \
+        }                                                                                                            \
+        mma_tile16_math<MATH, A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small)); \
+    } while (0)
+    if (NSTAGE == 2) {
+        // unrolled by two: the stage is a compile-time constant, so every LDS address of the loop is a loop-invariant
+        // register plus an immediate -- no vector-ALU instruction between the MFMAs (each one costs the matrix pipe about
+        // six cycles, tools/microbench/mfma_f32_16x16.hip; LDS reads, scalar instructions and waits cost nothing)
+        for (int kt = 0; kt < nkt; kt += 2) {
+            NPM_GEMM_TILE(kt, 0);
+            if (kt + 1 < nkt) NPM_GEMM_TILE(kt + 1, 1);
+        }
+    } else {
+        int stage = 0;
+        for (int kt = 0; kt < nkt; ++kt) {
             if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PW + B_PW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             if (kt + 2 < nkt) issue(kt + 2, stage == 0 ? 2 : stage - 1);
-        } else {
-            if (!(p.ablate & 4)) dma_barrier();
-            if (p.trace && kt == 0) t_first = __builtin_amdgcn_s_memtime();
-            if (kt + 1 < nkt && !(p.ablate & 1)) issue(kt + 1, (kt + 1) & 1);
+            const float *sA = smem + stage * STAGE;
+            const float *sB = sA + A_TILE;
+            stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+            if (KSUM && do_ksum) {
+                const float *st = (KSUM == 1 ? sB : sA) + (tid & 127);
+                for (int r = ks_row0; r < GK; r += 2 * ks_share) ks_acc += st[r * 128];
+            }
+            mma_tile16_math<MATH, A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
         }
-        const float *sA = smem + stage * STAGE;
-        const float *sB = sA + A_TILE;
-        stage = stage + 1 == NSTAGE ? 0 : stage + 1;
-        if (KSUM && do_ksum) {
-            const float *st = (KSUM == 1 ? sB : sA) + (tid & 127);          // both tiles are [16 k][128] here
-            for (int r = ks_row0; r < GK; r += 2 * ks_share) ks_acc += st[r * 128];
-        }
-        mma_tile16_math<MATH, A_KMAJ, B_KMAJ, TN, TM>(sA, sB, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
     }
+#undef NPM_GEMM_TILE
     if (MATH == 2) {
 #pragma unroll
         for (int i = 0; i < 2; ++i)
