@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(THREADS) kern_kind(long long *out, int trips) 
             else MFMA16(acc[g % 8]);
 #pragma unroll
             for (int i = 0; i < F; ++i) {
-                if (KIND == 1) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sc));
+                if (KIND == 1) asm volatile("s_add_u32 %0, %0, 3" : "+s"(sc) : : "scc");
                 else if (KIND == 2) asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(la));
                 else if (KIND == 3) asm volatile("s_nop 0");
                 else asm volatile("s_waitcnt lgkmcnt(0)");
