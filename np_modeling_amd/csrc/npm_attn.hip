@@ -209,8 +209,9 @@ mha_fwd_kernel(const MhaArgs p) {
     const unsigned lds_k = lds_offset(smem + wave * PPW * 256), lds_v = lds_k + 2 * TILE * 4;      // this wave's pieces, stage 0
     auto issue = [&](int t, int stage) {
         if (PIECES % 4 == 0 || wave * PPW < PIECES) {     // D = 16: two pieces per tile, waves 0 and 1 (PPW = 1)
-            dma_group<PPW>(descK, lds_k + stage * TILE * 4, t * kstep, vk);   // the tile's first row = the scalar offset: range-checked
-            dma_group<PPW>(descV, lds_v + stage * TILE * 4, t * vstep, vv);
+            const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);  // (called from the tile lambda the compiler no longer sees that t is uniform)
+            dma_group<PPW>(descK, lds_k + stage * TILE * 4, tu * kstep, vk);  // the tile's first row = the scalar offset: range-checked
+            dma_group<PPW>(descV, lds_v + stage * TILE * 4, tu * vstep, vv);
         }
     };
 
@@ -243,13 +244,17 @@ mha_fwd_kernel(const MhaArgs p) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
     if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
-    for (int t = 0; t < nt; ++t) {
+    // One key tile out of LDS stage STG.  The loop below is unrolled by two so that the stage is a compile-time constant: every
+    // LDS address of the tile is a loop-invariant register plus an immediate (32 vector-ALU adds per tile fewer -- each costs the
+    // matrix pipe its issue cycles, tools/microbench/mfma_f32_16x16.hip).
+    auto tile = [&](auto stage_c, const int t) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stage_c)::value;
         npm_tile::dma_barrier();                        // tile t has landed (every wave's pieces); nobody still reads the stage refilled next
         long long *tr = (TRACE && p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
         if (TRACE && p.trace && tid == 0 && t == (nt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime(); FENCE(); }
         STAMP(0);
-        if (t + 1 < nt) issue(t + 1, (t + 1) & 1);
-        const float *sK = smem + (t & 1) * TILE, *sV = smem + (2 + (t & 1)) * TILE;
+        if (t + 1 < nt) issue(t + 1, STG ^ 1);
+        const float *sK = smem + STG * TILE, *sV = smem + (2 + STG) * TILE;
         unsigned char mk[16];
         if (MASK) {                                     // requested now, used behind the 64 MFMAs of the score product
 #pragma unroll
@@ -258,7 +263,6 @@ mha_fwd_kernel(const MhaArgs p) {
 
         // ---- S^T[kv, q] = K Q^T: NG steps of (1 row read, 4 MFMAs), every read one step ahead of its use
         f32x16 S;
-        zero16(S);
         float4 fk[2];
         float ev[2][4];
         fk[0] = ld4(sK + rb[0]);
@@ -267,7 +271,12 @@ mha_fwd_kernel(const MhaArgs p) {
             if (g + 1 < NG) fk[(g + 1) & 1] = ld4(sK + rb[(g + 1) & 7] + T::row_imm(g + 1));
             else ldv<VEC>(sV + vb[0][0], ev[0]);                                 // first vector of the PV phase
             FENCE();
-            S = MFMA(fk[g & 1].x, qf[g].x, S);
+            if (g == 0) {                                                        // the first MFMA starts from the constant 0: nothing zeroes S
+                const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                S = MFMA(fk[0].x, qf[0].x, zero);
+            } else {
+                S = MFMA(fk[g & 1].x, qf[g].x, S);
+            }
             S = MFMA(fk[g & 1].y, qf[g].y, S);
             S = MFMA(fk[g & 1].z, qf[g].z, S);
             S = MFMA(fk[g & 1].w, qf[g].w, S);
@@ -347,6 +356,10 @@ mha_fwd_kernel(const MhaArgs p) {
             FENCE();
         }
         STAMP(3);
+    };
+    for (int t = 0; t < nt; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1);
     }
     if (blk_tr) blk_tr[12] = __builtin_amdgcn_s_memtime();
 
