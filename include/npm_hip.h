@@ -118,7 +118,7 @@ enum {
     NPM_TUNE_GEMM_GROUP_M = 2,
     NPM_TUNE_GEMM_BUF_EPILOGUE = 3,
     NPM_TUNE_CONV_DMA = 4,
-    NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never, 1 always, 2 (default) NN/NT */
+    NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never (default), 1 always, 2 NN / NT, 3 NT only */
     NPM_TUNE_LN_BWD_BLOCKS = 6,      /* blocks per CU of the LayerNorm backward grid (default 4) */
     NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
     NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, -1 unbalanced ceil(3 CUs / tiles) */
