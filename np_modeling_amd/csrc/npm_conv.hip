@@ -455,6 +455,7 @@ struct WgradArgs {
     int M, N, K;
     int tiles_m, tiles_n, splits, k_per_split;
     long slab;
+    KSync ksync;         // rendezvous of the co-resident blocks (npm_mfma_tile.h), slice == null: off
 };
 
 template <int WR>
@@ -574,6 +575,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
     // loop is unrolled by two): every LDS address is a loop-invariant register plus an immediate.
 #define NPM_WGRAD_TILE(KT, STG)                                                                                    \
     do {                                                                                                           \
+        ksync_wait(p.ksync, (KT), tid);                                                                            \
         /* tile KT is in LDS for every wave (the DMA pieces: vmcnt; the masked rows: lgkmcnt); the other stage is   \
            free.  The g stores of the tile before are this wave's youngest vector-memory operations: they stay in  \
            flight. */                                                                                              \
@@ -869,6 +871,12 @@ int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, flo
             hipStream_t s = npm::ctx().stream;
             npm::note_math(0);
             const int grid = (int)(tiles * splits);
+            // K rendezvous: all blocks resident at once (3 or 4 per CU), every split long enough
+            if (splits > 1 && grid <= (long)resident * npm::ctx().num_cus && npm::ksync_every() > 0 && kt_per >= 2 * npm::ksync_every()) {
+                a.ksync.slice = npm::ksync_slice();
+                a.ksync.every = npm::ksync_every();
+                a.ksync.epochs = (nkt - (splits - 1) * kt_per - 1) / a.ksync.every;
+            }
             if (tall) hipLaunchKernelGGL(conv_wgrad_relu_kernel<3>, dim3(grid), dim3(NTHREADS), 0, s, a);
             else hipLaunchKernelGGL(conv_wgrad_relu_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
             NPM_CHECK_LAUNCH();

@@ -31,6 +31,12 @@ void set_stream_nt(int on);
 bool stream_nt_enabled(size_t bytes);
 // the arithmetic the most recent matrix-product launch actually ran (npm_last_math): NPM_MATH_*
 void note_math(int mode);
+// K rendezvous of co-resident split-K blocks (npm_mfma_tile.h ksync_wait): a zeroed 1 KiB slice of counters for ONE launch on
+// the compute stream (a ring of slices, re-zeroed in stream order when it wraps), or null when the feature is off / unavailable
+unsigned *ksync_slice();
+int ksync_every();             // K tiles between rendezvous (NPM_TUNE_GEMM_KSYNC; 0 = off)
+void set_ksync_every(int every);
+void ksync_release();
 
 // Pool-backed scratch for split-K slabs and reduction partials; released on scope exit.
 // Safe because every launch goes to the single compute stream (stream-ordered reuse).

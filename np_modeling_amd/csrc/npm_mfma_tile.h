@@ -644,6 +644,36 @@ __device__ __forceinline__ void mma_tile16_math(const float *__restrict__ sA, co
     else mma_tile16<A_KMAJ, B_KMAJ, B_PITCH, A_PITCH>(sA, sB, arow, brow, half, acc);
 }
 
+// ---- K rendezvous of co-resident blocks ----------------------------------------------------------------------------
+// The blocks of a split-K launch that fits the chip at once (weight gradients: K = 131072 samples) stream the same operand
+// panels through their XCD's L2, each at its own pace; after a few hundred K tiles they are further apart than the L2 holds and
+// every panel is fetched from the Infinity Cache several times (15 GB per FFN weight-gradient launch against 2.7 GB algorithmic).
+// Every `every` K tiles thread 0 of each block checks in at a counter of its XCD group (blockIdx & 7, the XCD the dispatcher
+// gave it) and waits until the whole group has: a SOFT rendezvous -- bounded spinning, and the first block that gives up
+// raises a flag that ends all waiting for the launch, so a block that is not resident (another kernel holding CUs) costs one
+// timeout, never a hang.  Results do not depend on it.  Measured on the FFN weight gradients: L2 read requests to the fabric
+// 1.17e8 -> 6.2e7 per launch, 7.93 -> 7.65 ms.
+struct KSync {
+    unsigned *slice;     // this launch's counters: [8 groups][32 words], word 0 = arrivals, word 1 = "stop waiting"; or null
+    int every;           // K tiles between rendezvous, a power of two
+    int epochs;          // rendezvous every block of the launch reaches (the shortest split decides)
+};
+
+__device__ __forceinline__ void ksync_wait(const KSync &k, int kt, int tid) {
+    if (k.slice == nullptr || tid != 0 || kt <= 0 || (kt & (k.every - 1)) != 0 || kt / k.every > k.epochs) return;
+    unsigned *ctr = k.slice + (blockIdx.x & 7) * 32;
+    if (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+    const unsigned target = (unsigned)(kt / k.every) * ((gridDim.x - (blockIdx.x & 7) + 7) >> 3);
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) {
+        if (spin >= 256 || __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(ctr + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+    }
+}
+
 // Split-K factor for a grid of `tiles` output tiles over `nkt` K tiles.  All blocks of such a launch are
 // resident at once (`resident` fit a CU: 4 with the f32 MFMA, 3 / 2 with the split-bf16 modes) and run equally
 // long, so the launch lasts as long as the fullest CU: cost(s) = ceil(tiles * s / CUs) / s.  Candidates leave the

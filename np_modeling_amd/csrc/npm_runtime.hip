@@ -16,6 +16,37 @@ static int g_last_math = 0;
 void note_math(int mode) { g_last_math = mode; }
 int last_math() { return g_last_math; }
 
+// ---- K rendezvous counters (npm_mfma_tile.h ksync_wait) -------------------------------------------------------------
+namespace {
+constexpr int KSYNC_SLICES = 1024, KSYNC_SLICE_WORDS = 256;      // 1 KiB per launch: 8 groups x 32 words
+unsigned *g_ksync_ring = nullptr;
+int g_ksync_next = 0;
+int g_ksync_every = 128;
+}  // namespace
+
+int ksync_every() { return g_ksync_every; }
+void set_ksync_every(int every) { g_ksync_every = (every > 0 && (every & (every - 1)) == 0) ? every : 0; }
+
+unsigned *ksync_slice() {
+    if (g_ksync_every <= 0 || !ctx().ready) return nullptr;
+    const size_t bytes = (size_t)KSYNC_SLICES * KSYNC_SLICE_WORDS * sizeof(unsigned);
+    if (!g_ksync_ring) {
+        if (hipMalloc((void **)&g_ksync_ring, bytes) != hipSuccess) { g_ksync_ring = nullptr; (void)hipGetLastError(); return nullptr; }
+        g_ksync_next = KSYNC_SLICES;                             // zero the ring before its first use
+    }
+    if (g_ksync_next >= KSYNC_SLICES) {                          // every launch that used the ring is ahead of this memset in the stream
+        if (hipMemsetAsync(g_ksync_ring, 0, bytes, ctx().stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        g_ksync_next = 0;
+    }
+    return g_ksync_ring + (size_t)(g_ksync_next++) * KSYNC_SLICE_WORDS;
+}
+
+void ksync_release() {
+    if (g_ksync_ring) (void)hipFree(g_ksync_ring);
+    g_ksync_ring = nullptr;
+    g_ksync_next = 0;
+}
+
 Context &ctx() {
     static Context c;
     return c;
@@ -112,6 +143,7 @@ int npm_shutdown(void) {
     if (!c.ready) return NPM_OK;
     NPM_HIP(hipStreamSynchronize(c.stream));
     npm_pool_trim();
+    npm::ksync_release();
     NPM_HIP(hipStreamDestroy(c.stream));
     c = npm::Context();
     return NPM_OK;

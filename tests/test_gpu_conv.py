@@ -162,6 +162,34 @@ def test_conv_bwd_w_relu_is_deterministic(npm):
     np.testing.assert_array_equal(runs[0][1], runs[1][1])
 
 
+def test_conv_bwd_w_relu_rendezvous_changes_nothing(npm):
+    """The K rendezvous of the co-resident filter-gradient blocks (NPM_TUNE_GEMM_KSYNC) engages when every split is at least
+    256 K tiles long (C3-like sizes: here 2^20 pixels): dw, db and g are bit-equal with it off, on, and at a short interval."""
+    from np_modeling_amd import _C, device as D
+    lib = _C.lib()
+    n, h, w, c0, c1, k = 16, 256, 256, 64, 128, 3
+    x, dy, pre = D.empty([n, h, w, c0]), D.empty([n, h, w, c1]), D.empty([n, h, w, c1])
+    rng = np.random.default_rng(6)
+    row = rng.standard_normal(h * w * c1).astype(np.float32)
+    for i in range(n):                                       # cheap, non-repeating enough: rolled copies of one image
+        for dst, src in ((dy, np.roll(row, 7 * i)), (pre, np.roll(row, 11 * i + 3)), (x, np.roll(row[:h * w * c0], 5 * i + 1))):
+            src = np.ascontiguousarray(src)                  # (kept alive across the copy)
+            _C.check(lib.npm_h2d(dst.ptr + 4 * i * src.size, src.ctypes.data, 4 * src.size))
+    runs = {}
+    for every in (0, 128, 32):
+        _C.check(lib.npm_set_tuning(15, every))
+        try:
+            g, dw, db = D.empty([n, h, w, c1]), D.empty([k, k, c0, c1]), D.empty([c1])
+            _C.check(lib.npm_conv2d_bwd_w_relu(dy.ptr, pre.ptr, x.ptr, g.ptr, dw.ptr, db.ptr, n, h, w, c0, c1, k))
+            runs[every] = (dw.numpy().copy(), db.numpy().copy(), g.numpy()[::5, ::37, ::41].copy())
+        finally:
+            _C.check(lib.npm_set_tuning(15, 128))
+    for every in (128, 32):
+        for got, want in zip(runs[every], runs[0]):
+            np.testing.assert_array_equal(got, want)
+    assert np.isfinite(runs[0][0]).all() and np.abs(runs[0][0]).max() > 0
+
+
 def test_conv_rejects_even_kernel(npm):
     layer = npm.layers.Conv2D(channels=4, kernel_size=2)
     with pytest.raises(AssertionError):
