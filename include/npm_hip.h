@@ -127,7 +127,7 @@ enum {
     NPM_TUNE_ATTN_STAGGER = 11,      /* attention forward: s_sleep(127) units one of the two blocks of a CU waits at its start (default 1) */
     NPM_TUNE_CONV_WGRAD_FUSED = 13,  /* npm_conv2d_bwd_w_relu: 1 (default) ReLU backward inside the grad_w kernel, tile height picked; 2 / 3 the same with 128- / 192-row tiles; 0 two passes */
     NPM_TUNE_ATTN_BWD16 = 14,        /* attention backward, head size 128, saved scores: 1 (default) the 8-wave 16x16x4-MFMA kernel (two waves per SIMD), 0 the 4-wave 32x32x2 one */
-    NPM_TUNE_GEMM_KSYNC = 15,        /* K tiles between the soft rendezvous of the co-resident blocks of a split-K launch (GEMM weight gradients, Conv2D filter gradient): a power of two, default 128; 0 off */
+    NPM_TUNE_KSYNC = 15,             /* K tiles between the soft rendezvous of the co-resident split-K blocks of the fused Conv2D filter gradient: a power of two, default 128; 0 off */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
     NPM_TUNE_GEMM_ABLATE = 99
 };

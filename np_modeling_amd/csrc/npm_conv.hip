@@ -575,7 +575,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
     // loop is unrolled by two): every LDS address is a loop-invariant register plus an immediate.
 #define NPM_WGRAD_TILE(KT, STG)                                                                                    \
     do {                                                                                                           \
-        ksync_wait(p.ksync, (KT), tid);                                                                            \
+        ksync_wait(p.ksync, (KT));                                                                                 \
         /* tile KT is in LDS for every wave (the DMA pieces: vmcnt; the masked rows: lgkmcnt); the other stage is   \
            free.  The g stores of the tile before are this wave's youngest vector-memory operations: they stay in  \
            flight. */                                                                                              \

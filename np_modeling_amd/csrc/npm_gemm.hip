@@ -45,7 +45,6 @@ struct GemmArgs {
     int wide;        // 128 x 256 block tile (2 x 4 waves) instead of 128 x 128
     int ablate;      // TIMING-ONLY diagnostics (results are wrong): 1 skip operand loads, 2 skip LDS stores, 4 skip barriers, 8 skip the epilogue
     long slab;       // split-K: batch * M * N
-    KSync ksync;     // rendezvous of the co-resident blocks of a split-K launch (npm_mfma_tile.h), slice == null: off
     Epilogue e;
 };
 
@@ -255,7 +254,6 @@ sgemm_glds_kernel(const GemmArgs p) {
     // to be refilled; the next tile goes out, then the 32 MFMAs
 #define NPM_GEMM_TILE(KT, STG)                                                                                       \
     do {                                                                                                             \
-        ksync_wait(p.ksync, (KT), tid);                                                                              \
         if (!(p.ablate & 4)) dma_barrier();                                                                          \
         if (p.trace && (KT) == 0) t_first = __builtin_amdgcn_s_memtime();                                            \
         if ((KT) + 1 < nkt && !(p.ablate & 1)) issue((KT) + 1, (STG) ^ 1);                                           \
@@ -459,7 +457,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         case NPM_TUNE_ATTN_STAGGER: return npm_attn_set_stagger(value);
         case NPM_TUNE_ATTN_BWD16: return npm_attn_set_bwd16(value);
-        case NPM_TUNE_GEMM_KSYNC: npm::set_ksync_every(value); return NPM_OK;
+        case NPM_TUNE_KSYNC: npm::set_ksync_every(value); return NPM_OK;
         case NPM_TUNE_STREAM_NT: npm::set_stream_nt(value); return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }
@@ -563,13 +561,6 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     const long grid = tiles * splits;
     NPM_ARG(grid < (1L << 31));
     hipStream_t stream = npm::ctx().stream;
-    // K rendezvous (npm_mfma_tile.h): split-K launches of the exact-f32 kernel whose blocks are all resident at once (4 per CU)
-    if (splits > 1 && a.math == 0 && !want_colsum && !a.wide && grid <= 4L * npm::ctx().num_cus && npm::ksync_every() > 0 &&
-        kt_per_split >= 2 * npm::ksync_every()) {
-        a.ksync.slice = npm::ksync_slice();
-        a.ksync.every = npm::ksync_every();
-        a.ksync.epochs = (nkt - (splits - 1) * kt_per_split - 1) / a.ksync.every;      // the last split is the shortest
-    }
     // Column sums of the stored C: taken in the epilogue of the LDS-DMA kernel when it is eligible,
     // otherwise by a separate pass over C (small / unaligned shapes).
     const long a_span = (a_kmaj ? (long)BM * g->lda + g->k : (long)a.k_per_split * g->lda + BM) * 4;

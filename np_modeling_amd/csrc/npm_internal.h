@@ -34,7 +34,7 @@ void note_math(int mode);
 // K rendezvous of co-resident split-K blocks (npm_mfma_tile.h ksync_wait): a zeroed 1 KiB slice of counters for ONE launch on
 // the compute stream (a ring of slices, re-zeroed in stream order when it wraps), or null when the feature is off / unavailable
 unsigned *ksync_slice();
-int ksync_every();             // K tiles between rendezvous (NPM_TUNE_GEMM_KSYNC; 0 = off)
+int ksync_every();             // K tiles between rendezvous (NPM_TUNE_KSYNC; 0 = off)
 void set_ksync_every(int every);
 void ksync_release();
 

@@ -659,11 +659,13 @@ struct KSync {
     int epochs;          // rendezvous every block of the launch reaches (the shortest split decides)
 };
 
-__device__ __forceinline__ void ksync_wait(const KSync &k, int kt, int tid) {
-    if (k.slice == nullptr || tid != 0 || kt <= 0 || (kt & (k.every - 1)) != 0 || kt / k.every > k.epochs) return;
-    unsigned *ctr = k.slice + (blockIdx.x & 7) * 32;
+// The rendezvous itself: out of line on purpose -- inlined into a K loop its spin loop (and the per-lane test in front of it) cost
+// every launch of the kernel 1.4 %, the ones that never rendezvous included (A/B of the two builds in one session).
+__device__ __attribute__((noinline)) void ksync_rendezvous(unsigned *slice, unsigned epoch) {
+    if (threadIdx.x != 0) return;
+    unsigned *ctr = slice + (blockIdx.x & 7) * 32;
     if (__hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
-    const unsigned target = (unsigned)(kt / k.every) * ((gridDim.x - (blockIdx.x & 7) + 7) >> 3);
+    const unsigned target = epoch * ((gridDim.x - (blockIdx.x & 7) + 7) >> 3);
     __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     for (int spin = 0; __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target; ++spin) {
         if (spin >= 256 || __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
@@ -672,6 +674,12 @@ __device__ __forceinline__ void ksync_wait(const KSync &k, int kt, int tid) {
         }
         __builtin_amdgcn_s_sleep(8);
     }
+}
+
+// In the K loop: wave-uniform tests only (scalar instructions cost the matrix pipe nothing), then the call.
+__device__ __forceinline__ void ksync_wait(const KSync &k, int kt) {
+    if (k.slice != nullptr && kt > 0 && (kt & (k.every - 1)) == 0 && kt / k.every <= k.epochs)
+        ksync_rendezvous(k.slice, (unsigned)(kt / k.every));
 }
 
 // Split-K factor for a grid of `tiles` output tiles over `nkt` K tiles.  All blocks of such a launch are

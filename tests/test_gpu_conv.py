@@ -163,7 +163,7 @@ def test_conv_bwd_w_relu_is_deterministic(npm):
 
 
 def test_conv_bwd_w_relu_rendezvous_changes_nothing(npm):
-    """The K rendezvous of the co-resident filter-gradient blocks (NPM_TUNE_GEMM_KSYNC) engages when every split is at least
+    """The K rendezvous of the co-resident filter-gradient blocks (NPM_TUNE_KSYNC) engages when every split is at least
     256 K tiles long (C3-like sizes: here 2^20 pixels): dw, db and g are bit-equal with it off, on, and at a short interval."""
     from np_modeling_amd import _C, device as D
     lib = _C.lib()

@@ -123,31 +123,6 @@ def test_split_k_tall(D, split):
     np.testing.assert_array_equal(c.numpy(), c_again.numpy())       # reproducible
 
 
-@pytest.mark.parametrize('every', [0, 16, 128])
-def test_split_k_rendezvous_changes_nothing(D, every):
-    """The K rendezvous of co-resident split-K blocks (NPM_TUNE_GEMM_KSYNC, include/npm_hip.h) is a pacing device: the
-    weight gradient and the bias sum are bit-equal with it off, at the default interval and at a short one (many epochs,
-    uneven last split), for a launch whose blocks are all resident and for one whose last split is the shortest."""
-    from np_modeling_amd import _C
-    lib = _C.lib()
-    rng = np.random.default_rng(12)
-    out = {}
-    for m, n, k in ((256, 384, 16 * 1041), (128, 128, 16 * 700)):
-        a = D.from_host(rng.standard_normal((k, m)).astype(np.float32))
-        b = D.from_host(rng.standard_normal((k, n)).astype(np.float32))
-        for setting in (0, every):
-            _C.check(lib.npm_set_tuning(15, setting))
-            try:
-                c, bs = D.empty([m, n]), D.empty([n])
-                D.gemm(m, n, k, D.Mat(a, m), D.Mat(b, n), D.Mat(c, n), trans_a=True, bsum_out=bs)
-                out[(m, setting)] = (c.numpy().copy(), bs.numpy().copy())
-            finally:
-                _C.check(lib.npm_set_tuning(15, 128))
-        np.testing.assert_array_equal(out[(m, 0)][0], out[(m, every)][0])
-        np.testing.assert_array_equal(out[(m, 0)][1], out[(m, every)][1])
-        assert_close(out[(m, every)][0], a.numpy().astype(np.float64).T @ b.numpy().astype(np.float64), tol=3e-6)
-
-
 def test_batched_head_strided(D):
     """q k^T and p v addressed as head slices of [B, S, H, D] (no transposes)."""
     rng = np.random.default_rng(5)
