@@ -311,12 +311,19 @@ conv_fwd_glds_kernel(const ConvArgs p) {
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
     if (nkt > 0) NPM_CONV_ISSUE(0, 0);
     prio_low(p.e.prio & 1);
-    for (int kt = 0; kt < nkt; ++kt) {
-        dma_barrier();
-        if (kt + 1 < nkt) NPM_CONV_ISSUE(kt + 1, (kt + 1) & 1);
-        const float *sA = smem + (kt & 1) * STAGE;
-        mma_tile16_math<MATH, true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small));
+    // unrolled by two: compile-time LDS stages, no vector-ALU address arithmetic between the MFMAs (npm_gemm.hip)
+#define NPM_CONV_TILE(KT, STG)                                                                               \
+    do {                                                                                                     \
+        dma_barrier();                                                                                       \
+        if ((KT) + 1 < nkt) NPM_CONV_ISSUE((KT) + 1, (STG) ^ 1);                                             \
+        const float *sA = smem + (STG) * STAGE;                                                              \
+        mma_tile16_math<MATH, true, false, TN>(sA, sA + A_TILE, arow, brow, half, acc, reinterpret_cast<f32x16 (&)[2][2]>(small)); \
+    } while (0)
+    for (int kt = 0; kt < nkt; kt += 2) {
+        NPM_CONV_TILE(kt, 0);
+        if (kt + 1 < nkt) NPM_CONV_TILE(kt + 1, 1);
     }
+#undef NPM_CONV_TILE
 #undef NPM_CONV_ISSUE
     if (MATH == 2) {
 #pragma unroll
