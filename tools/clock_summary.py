@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Summarise a tools/clock_sampler.sh log: the card under load (highest power), its clock and power while loaded."""
+"""Summarise a tools/clock_sampler.sh log: the card under load (most samples above 800 W), its clock and power while loaded."""
 import re
 import statistics
 import sys
@@ -9,7 +9,8 @@ n = max(len(r) for r in rows)
 rows = [r for r in rows if len(r) == n]
 watts = lambda cell: int(re.findall(r'(\d+) W', cell)[0])
 mhz = lambda cell: int(re.findall(r'(\d+) MHz', cell)[0])
-card = max(range(n), key=lambda i: max(watts(r[i]) for r in rows))
+# the card under THIS load: loaded for the longest part of the log (another tenant's card of the host may peak higher for a moment)
+card = max(range(n), key=lambda i: sum(watts(r[i]) > 800 for r in rows))
 pw = [watts(r[card]) for r in rows]
 ck = [mhz(r[card]) for r in rows]
 hot = [(c, p) for c, p in zip(ck, pw) if p > 0.8 * max(pw)]
