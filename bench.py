@@ -162,8 +162,8 @@ def load_pmc_traffic(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=256, help='per-GPU batch')
     ap.add_argument('--seq', type=int, default=512)
     ap.add_argument('--features', type=int, default=1024)
