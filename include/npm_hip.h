@@ -253,6 +253,10 @@ typedef struct npm_mha_core {
 int npm_mha_core_supported(int head_dim);          /* 1 when npm_mha_core_fwd/bwd take this head dimension */
 int npm_mha_core_fwd(const npm_mha_core *c);
 int npm_mha_core_bwd(const npm_mha_core *c);
+/* Which kernel the most recent npm_mha_core_fwd / npm_mha_core_bwd call launched, as "<kernel> D=<head_dim> mask=<0|1>
+ * scores=<0|1>" (e.g. "mha_bwd16_kernel D=128 mask=0 scores=1"); "" before the first call.  Tests use it to assert that
+ * a comparison exercised the kernel it names. */
+const char *npm_last_attn_kernel(void);
 /* Diagnostics: when buf != NULL every block of the backward kernel writes 16 words of s_memtime stamps of ONE of its
  * tiles (phase boundaries: tile start, after S, dP, dV, dK, the dS barrier, dQ, the dQ stores; word 8: next tile's start)
  * to buf[blockIdx * 16 ..]; NULL switches it off. */

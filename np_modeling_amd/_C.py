@@ -139,6 +139,7 @@ _SPECIAL = {
     'npm_abi_version': (C.c_int, []),
     'npm_last_error': (C.c_char_p, []),
     'npm_stream': (C.c_void_p, []),
+    'npm_last_attn_kernel': (C.c_char_p, []),
 }
 
 COMM_SIGNATURES = {
@@ -296,6 +297,11 @@ def last_math() -> str:
     """The arithmetic the most recent matrix-product launch actually ran (include/npm_hip.h npm_last_math)."""
     value = lib().npm_last_math()
     return next(name for name, v in MATH_MODES.items() if v == value)
+
+
+def last_attn_kernel() -> str:
+    """What the most recent fused attention call launched (include/npm_hip.h npm_last_attn_kernel)."""
+    return lib().npm_last_attn_kernel().decode()
 
 
 def comm_lib():

@@ -1023,6 +1023,11 @@ mha_bwd16_kernel(const MhaArgs p) {
 long long *g_attn_trace = nullptr;
 int g_attn_stagger = 1;
 int g_attn_bwd16 = 1;          // NPM_TUNE_ATTN_BWD16: head size 128 with saved scores on the 8-wave 16 x 16 x 4 kernel
+char g_attn_last[96] = "";     // npm_last_attn_kernel: what the most recent npm_mha_core_* call launched
+
+void note_kernel(const char *name, int d, bool mask, bool saved) {
+    snprintf(g_attn_last, sizeof g_attn_last, "%s D=%d mask=%d scores=%d", name, d, (int)mask, (int)saved);
+}
 
 // delta[b, h, s] = scale * sum_d dO[b, s, h, d] * O[b, s, h, d]: half a wavefront (32 lanes x float4) per (b, s, h) row.
 __global__ void __launch_bounds__(256)
@@ -1064,6 +1069,7 @@ int launch_fwd(const MhaArgs &a, hipStream_t s) {
     else if (mask) launch_fwd_instance<D, true, false>(a, grid, s);
     else if (save) launch_fwd_instance<D, false, true>(a, grid, s);
     else launch_fwd_instance<D, false, false>(a, grid, s);
+    note_kernel("mha_fwd_kernel", D, mask, save);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }
@@ -1081,10 +1087,12 @@ int launch_bwd(const MhaArgs &a, hipStream_t s) {
     // Saved scores already CARRY the mask (the forward stored -inf at every masked position, so P = exp2(-inf) = 0
     // there): the backward needs the mask bytes only when it recomputes q.k.  One instance less per head size -- the
     // one whose 16 extra byte loads per tile did not fit the register file at D = 128.
-    if (saved && D == 128 && g_attn_bwd16 && !a.trace) hipLaunchKernelGGL(mha_bwd16_kernel, dim3(grid), dim3(512), 0, s, a);
+    const bool wide = saved && D == 128 && g_attn_bwd16 && !a.trace;
+    if (wide) hipLaunchKernelGGL(mha_bwd16_kernel, dim3(grid), dim3(512), 0, s, a);
     else if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
     else if (mask) launch_bwd_instance<D, true, false>(a, grid, s);
     else launch_bwd_instance<D, false, false>(a, grid, s);
+    note_kernel(wide ? "mha_bwd16_kernel" : "mha_bwd_kernel", D, mask && !saved, saved);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }
@@ -1136,6 +1144,8 @@ int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
 extern "C" int npm_debug_attn_trace(long long *buf) { g_attn_trace = buf; return NPM_OK; }
 extern "C" int npm_attn_set_stagger(int units) { g_attn_stagger = units < 0 ? 0 : units; return NPM_OK; }
 extern "C" int npm_attn_set_bwd16(int on) { g_attn_bwd16 = on != 0; return NPM_OK; }
+
+extern "C" const char *npm_last_attn_kernel(void) { return g_attn_last; }
 
 extern "C" int npm_mha_core_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
 

@@ -207,6 +207,97 @@ def gen_train(layers, optimizer, train):
         save('train_mlp_' + opt_name, x=x, targets=t, losses=losses, lr=np.float64(1e-4), **final)
 
 
+def gen_refshape(layers, name):
+    """Fixtures at the reference's own test shapes and at the head sizes the fused attention kernels take
+    (recipes, flow and rationale: tests/refshapes.py).  Stored: the reference's outputs as float32, the raw gradients
+    its backward hands to ``optimizer_.update`` (a recording optimizer), the parameters after its own SGD step where
+    the reference's tests assert them (MHA, Conv2D), and CRC-32s of the rebuilt inputs / parameters."""
+    import copy
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    import refshapes as R
+    case = R.CASES[name]
+    kind = case['kind']
+    inp = R.draw_inputs(case)
+    f32 = lambda a: np.asarray(a, dtype=np.float32)
+    arrays = {k + '_crc': np.int64(R.crc(v)) for k, v in inp.items()}
+    arrays['lr'] = np.float64(case.get('lr', 0.0))
+    if kind == 'conv':
+        layer = layers.Conv2D(channels=case['channels'], kernel_size=case['k'])
+        y = layer(inp['x'])
+        arrays.update(w0=layer.w.copy(), b0=layer.b.copy(), y=f32(y))
+        dy = R.mse_grad(y, inp['targets'])
+        rec, recorder = copy.deepcopy(layer), R.GradRecorder()
+        dx = rec(dy, backprop=True, optimizer_=recorder)
+        arrays.update(dx_samples=f32(dx[list(R.CONV_DX_SAMPLES)]), dx_batch_sum=np.asarray(dx, dtype=np.float64).sum(axis=0),
+                      dw=f32(recorder.grads[(id(rec), '_w')]), db=f32(recorder.grads[(id(rec), '_b')]))
+        upd = copy.deepcopy(layer)
+        upd(dy, backprop=True, learning_rate=case['lr'])
+        arrays.update(w1=upd.w, b1=upd.b, dy_crc=np.int64(R.crc(dy)))
+        save(name, **arrays)
+        return
+    if kind == 'dense':
+        layer = layers.Dense(units=case['units'])
+        y = layer(inp['x'])
+        lin = layer.linear
+        arrays.update(w0=lin.w.copy(), b0=lin.b.copy(), y=f32(y))
+        dy = R.mse_grad(y, inp['targets'])
+        rec, recorder = copy.deepcopy(layer), R.GradRecorder()
+        dx = rec(dy, backprop=True, optimizer_=recorder)
+        arrays.update(dx=f32(dx), dw=f32(recorder.grads[(id(rec.linear), '_w')]), db=f32(recorder.grads[(id(rec.linear), '_b')]))
+        layer(dy, backprop=True, learning_rate=case['lr'])
+        arrays.update(w1=lin.w, b1=lin.b, dy_crc=np.int64(R.crc(dy)))
+        save(name, **arrays)
+        return
+    if kind == 'softmax':
+        layer = layers.Softmax()
+        y = layer(inp['x'])
+        dy = R.mse_grad(y, inp['targets'])
+        arrays.update(y=f32(y), dx=f32(layer(dy, backprop=True)), dy_crc=np.int64(R.crc(dy)))
+        save(name, **arrays)
+        return
+    if kind == 'layernorm':
+        layer = layers.LayerNormalization()
+        layer(inp['x'])
+        params = R.bound_params(case)
+        layer._gamma, layer._beta, layer._epsilon = params['gamma'].copy(), params['beta'].copy(), R.LN_EPS
+        z = layer(inp['x'])
+        dz = R.mse_grad(z, inp['targets'])
+        rec, recorder = copy.deepcopy(layer), R.GradRecorder()
+        dx = rec(dz, backprop=True, optimizer_=recorder)
+        arrays.update(z=f32(z), dx=f32(dx), dgamma=f32(recorder.grads[(id(rec), '_gamma')]), dbeta=f32(recorder.grads[(id(rec), '_beta')]))
+        layer(dz, backprop=True, learning_rate=case['lr'])
+        arrays.update(gamma1=f32(layer._gamma), beta1=f32(layer._beta), dy_crc=np.int64(R.crc(dz)))
+        save(name, **arrays)
+        return
+    if kind == 'mha':
+        layer = layers.MultiHeadAttention(num_heads=case['heads'])
+    elif kind == 'encoder':
+        layer = layers.TransformerEncoder(num_heads=case['heads'], hidden_units=case['hidden'], norm_first=case['norm_first'])
+    else:
+        layer = layers.TransformerDecoder(num_heads=case['heads'], hidden_units=case['hidden'], norm_first=case['norm_first'])
+    args = (inp['query'], inp['kv']) if 'kv' in inp else (inp['query'],)
+    layer(*args)                                   # lazy initialisation; these draws are replaced below
+    params = R.bound_params(case)
+    R.bind(layer, case, params)
+    out = layer(*args)
+    dy = R.mse_grad(out, inp['targets'])
+    arrays.update(out=f32(out), dy_crc=np.int64(R.crc(dy)), params_crc=np.int64(R.crc(np.concatenate([v.ravel() for v in params.values()]))))
+    rec, recorder = copy.deepcopy(layer), R.GradRecorder()
+    grads_in = rec(dy, backprop=True, optimizer_=recorder)
+    if kind == 'mha':
+        arrays.update(dquery=f32(grads_in[0]), dkey=f32(grads_in[1]), dvalue=f32(grads_in[2]))
+    elif kind == 'encoder':
+        arrays.update(dx=f32(grads_in))
+    else:
+        arrays.update(dq=f32(grads_in[0]), dkv=f32(grads_in[1]))
+    arrays.update({'grad_' + k: f32(v) for k, v in recorder.named(rec, case).items()})
+    if case.get('updated'):                        # attentions_test.py:72-85 asserts the updated parameters
+        upd = copy.deepcopy(layer)
+        upd(dy, backprop=True, learning_rate=case['lr'])
+        arrays.update({n + '1': f32(getattr(upd, '_' + n)) for n in R.MHA_NAMES})
+    save(name, **arrays)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     layers, optimizer, loss, train = _ref()
@@ -227,6 +318,10 @@ def main():
     gen_losses(loss)
     gen_softmax_ce(layers, loss)
     gen_train(layers, optimizer, train)
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tests'))
+    import refshapes
+    for name in refshapes.CASES:
+        gen_refshape(layers, name)
 
 
 if __name__ == '__main__':

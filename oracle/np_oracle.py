@@ -33,6 +33,29 @@ import numpy as np
 
 Array = np.ndarray
 
+# The dtype of the spots where the reference's NumPy expressions promote to fp64 (module docstring).  ``None`` keeps the
+# reference's promotions; ``compute_in(np.float32)`` evaluates the same formulas in fp32 end to end -- the noise floor of a
+# legitimate fp32 implementation, which tests/test_gpu_reference_form.py sets beside the product's error.
+COMPUTE_DTYPE = None
+
+
+class compute_in:
+    def __init__(self, dtype):
+        self.dtype = dtype
+
+    def __enter__(self):
+        global COMPUTE_DTYPE
+        self.saved, COMPUTE_DTYPE = COMPUTE_DTYPE, self.dtype
+        return self
+
+    def __exit__(self, *exc):
+        global COMPUTE_DTYPE
+        COMPUTE_DTYPE = self.saved
+
+
+def _wide(a) -> Array:
+    return np.asarray(a, dtype=COMPUTE_DTYPE or np.float64)
+
 
 # --------------------------------------------------------------------------- #
 # initializer (reference layers/layer.py:57-60)
@@ -104,8 +127,8 @@ def softmax_bwd(y: Array, dy: Array, verbatim: bool = False) -> Array:
         jac = jac - np.expand_dims(y, axis=rank - 1)
         jac = jac * np.expand_dims(y, axis=rank)
         return np.einsum('...a,...ba->...b', dy, jac)
-    y64 = y.astype(np.float64)
-    dy64 = np.asarray(dy, dtype=np.float64)
+    y64 = _wide(y)
+    dy64 = _wide(dy)
     inner = (dy64 * y64).sum(axis=-1, keepdims=True)
     return y64 * (dy64 - inner)
 
@@ -146,9 +169,9 @@ def layernorm_bwd(x, gamma, eps, cache, dz, verbatim: bool = False):
                np.expand_dims(dvar_dx, rank) * np.expand_dims(centered, rank - 1))
         dx = np.einsum('...a,...ab->...b', g, jac)
     else:
-        g64 = g.astype(np.float64)
-        yh64 = yhat.astype(np.float64)
-        rstd = 1.0 / np.sqrt(var.astype(np.float64) + eps)
+        g64 = _wide(g)
+        yh64 = _wide(yhat)
+        rstd = 1.0 / np.sqrt(_wide(var) + _wide(eps))
         dx = rstd * (g64 - g64.mean(axis=-1, keepdims=True) -
                      yh64 * (g64 * yh64).mean(axis=-1, keepdims=True))
     return dx, dgamma, dbeta
@@ -160,7 +183,7 @@ def layernorm_bwd(x, gamma, eps, cache, dz, verbatim: bool = False):
 def _pad_same(x: Array, k: int) -> Array:
     n, h, w, c = x.shape
     p = k // 2
-    padded = np.zeros([n, h + k - 1, w + k - 1, c])          # fp64, as conv.py:97
+    padded = np.zeros([n, h + k - 1, w + k - 1, c], dtype=COMPUTE_DTYPE or np.float64)          # fp64, as conv.py:97
     padded[:, p:h + p, p:w + p, :] = x
     return padded
 
@@ -171,7 +194,7 @@ def conv2d_fwd(x: Array, filt: Array) -> Array:
     k, k2, fc0, c1 = filt.shape
     assert k == k2 and fc0 == c0 and k % 2 == 1
     xp = _pad_same(x, k)
-    out = np.zeros([n, h, w, c1])
+    out = np.zeros([n, h, w, c1], dtype=COMPUTE_DTYPE or np.float64)
     for i in range(k):
         for j in range(k):
             tap = xp[:, i:i + h, j:j + w, :].reshape(n * h * w, c0)
@@ -192,7 +215,7 @@ def conv2d_grad_w(dy: Array, x: Array, k: int) -> Array:
     assert dy.shape[:3] == x.shape[:3] and k % 2 == 1
     xp = _pad_same(x, k)
     rhs = dy.reshape(n * h * w, c1)
-    dw = np.zeros([k, k, c0, c1])
+    dw = np.zeros([k, k, c0, c1], dtype=COMPUTE_DTYPE or np.float64)
     for i in range(k):
         for j in range(k):
             lhs = xp[:, i:i + h, j:j + w, :].reshape(n * h * w, c0).T
@@ -258,6 +281,8 @@ def mha_fwd(p: Dict[str, Array], query: Array, key: Optional[Array] = None,
         v = (value.reshape(b * skv, -1) @ p['wv'].reshape(h * dv, -1).T).reshape(b, skv, h, dv) + p['bv']
         att = np.matmul(q.transpose(0, 2, 1, 3), k.transpose(0, 2, 3, 1))
     scaled = (1.0 / np.sqrt(dk)) * att            # np.float64 scalar -> fp64 under NumPy 2
+    if COMPUTE_DTYPE is not None:
+        scaled = scaled.astype(COMPUTE_DTYPE)
     if mask is not None:                          # attentions.py:105-107 as written (see attention_core_fwd)
         scaled = np.where(mask, scaled, float('-inf'))
     scores = softmax_fwd(scaled)                  # [b, h, sq, skv]
@@ -298,6 +323,8 @@ def mha_bwd(p: Dict[str, Array], cache: Dict[str, Array], dy: Array, verbatim: b
         dv = np.matmul(scores.transpose(0, 1, 3, 2), dvalues).transpose(0, 2, 1, 3)
     dscaled = softmax_bwd(scores, dscores, verbatim=verbatim)
     datt = dscaled / np.sqrt(dk)
+    if COMPUTE_DTYPE is not None:
+        datt = datt.astype(COMPUTE_DTYPE)
     if verbatim:
         dq = np.einsum('...abc,...cad->...bad', datt, k)
         dk_ = np.einsum('...abc,...bad->...dbc', q, datt)

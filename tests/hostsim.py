@@ -378,6 +378,10 @@ class HostSim:
     def npm_set_tuning(self, knob, value):
         return 0
 
+    def npm_last_attn_kernel(self):
+        last = [c for c in self.calls if c.startswith('npm_mha_core_')]
+        return (('hostsim ' + last[-1]) if last else '').encode()
+
 
 def install():
     """Install a fresh simulator as the product's library handle; returns it."""

@@ -452,6 +452,16 @@ def test_mha_fused_core_path_on_simulator(npm, masked):
             assert_close(getattr(layer, '_' + n), p[n] - 0.1 * grads[n], tol=1e-6, what=n)
 
 
+@pytest.mark.parametrize('name', ['ref_mha_self_d16', 'ref_mha_cross_d64', 'ref_encoder_prenorm', 'ref_decoder_postnorm',
+                                  'ref_conv_k3', 'ref_dense', 'ref_softmax', 'ref_layernorm'])
+def test_reference_shape_fixtures_on_simulator(npm, name):
+    """The host side of tests/test_gpu_refshapes.py: binding parameters into private attributes, deep copies, recording
+    optimizers and the composite layers' descriptors, at the reference's own test shapes, against reference outputs."""
+    import refshape_runner as RR
+    got, ref = RR.run(npm, name)
+    RR.compare(got, ref, tol=1e-5)
+
+
 def test_dropout_device_rng_plumbing(npm):
     """set_dropout_rng('device'): the mask comes from npm_dropout_philox, `_mask` is read back lazily, successive
     calls advance the offset, 'host' restores the reference's np.random.binomial draw."""
