@@ -234,20 +234,28 @@ def main():
     timer = None if args.no_kernel_timer else D.KernelTimer()
     if timer is not None:
         timer.__enter__()
+    marks = [D.Event() for _ in range(args.steps + 1)]   # one HIP event per step boundary, on the compute stream
+    marks[0].record()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     D.synchronize()
+    local_elapsed = time.perf_counter() - t0             # this rank alone, before it waits for the others
     if comm.active:
         comm.barrier()
     elapsed = time.perf_counter() - t0
     if timer is not None:
         timer.__exit__(None, None, None)
+    step_ms = sorted(marks[i].elapsed_ms(marks[i + 1]) for i in range(args.steps))
     exchange_stats = comm.stats() if rccl else None
     if rccl:
         comm.stats_enable(False)
+    rank_ms = None
     if comm.active:
         elapsed = comm.allreduce_scalar(elapsed, parallel.MAX)
+        rank_ms = {'max': 1e3 * comm.allreduce_scalar(local_elapsed, parallel.MAX) / max(args.steps, 1),
+                   'min': -1e3 * comm.allreduce_scalar(-local_elapsed, parallel.MAX) / max(args.steps, 1)}
 
     total_samples = args.batch * world * args.steps
     value = total_samples / elapsed
@@ -258,6 +266,13 @@ def main():
         'value': value, 'unit': 'samples/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': 1e3 * elapsed / args.steps, 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None,
+        # `value` / `ms_per_step` are the contract's wall-clock figures (barrier + synchronize on both sides, max over
+        # ranks, mean over the K steps).  Beside them, rank 0's per-step DEVICE times (HIP events on the compute stream
+        # at every step boundary): the median is what a step costs once the clocks have settled.
+        'step_ms_device': ({'median': step_ms[len(step_ms) // 2] if len(step_ms) % 2 else 0.5 * (step_ms[len(step_ms) // 2 - 1] + step_ms[len(step_ms) // 2]),
+                            'min': step_ms[0], 'max': step_ms[-1], 'mean': sum(step_ms) / len(step_ms),
+                            'note': 'HIP events at step boundaries, rank 0; the kernel timer\'s own events are inside these intervals'}
+                           if step_ms else None),
         'dtype': 'f32' if args.math == 'f32' else f'f32 ({args.math}: {MATH_NOTE[args.math]}, fp32 accumulate)',
         'math': args.math, 'data': 'synthetic N(0,1) fp32 inputs resident in HBM; random-init '
         'weights (reference initializer scaled by 1/sqrt(fan_in))',
@@ -276,6 +291,11 @@ def main():
                               'launcher': 'external (RANK/WORLD_SIZE in the environment)' if 'NPM_RENDEZVOUS_FILE' not in os.environ
                               else 'np_modeling_amd.launch (self-launched child ranks)', 'torch_imported': 'torch' in sys.modules,
                               'device': npm._C.device_index(), 'visible_devices': npm._C.visible_devices()}
+        result['exchange']['cpu_placement'] = parallel.PLACEMENT
+        if rank_ms is not None:
+            # every rank's own wall clock over the K steps (before the closing barrier): the spread is what the slowest
+            # rank costs the others in a weak-scaling run
+            result['exchange']['ms_per_step_over_ranks'] = rank_ms
         if exchange_stats is not None:
             # rank 0's view, HIP events (include/npm_comm.h npm_comm_stats): allreduce_ms = time the collectives held the
             # communication stream (overlaps backward); exposed_ms = time the compute stream stood still waiting for them
@@ -284,9 +304,12 @@ def main():
                 'bytes_per_step': exchange_stats['bytes'] / k, 'flushes_per_step': exchange_stats['allreduce_calls'] / k,
                 'allreduce_ms': exchange_stats['allreduce_ms'] / k, 'exposed_ms': exchange_stats['exposed_ms'] / k,
                 'exposed_frac_of_step': exchange_stats['exposed_ms'] / (1e3 * elapsed) if elapsed > 0 else None,
+                # the flush issued after the LAST gradient of a backward: nothing is left to overlap it
+                'last_flush_ms': exchange_stats['last_allreduce_ms'] / k,
                 'busbw_GBps': (2 * (world - 1) / world * exchange_stats['bytes'] / (exchange_stats['allreduce_ms'] * 1e-3) / 1e9
                                if world > 1 and exchange_stats['allreduce_ms'] > 0 else None),
-                'note': 'per step, rank 0; allreduce_ms overlaps backward, exposed_ms is what the compute stream waited'})
+                'note': 'per step, rank 0; allreduce_ms overlaps backward, exposed_ms is what the compute stream waited, '
+                        'last_flush_ms is the duration of the final collective of each backward (included in allreduce_ms)'})
 
     if timer is not None:
         summary = timer.summary()
@@ -383,14 +406,16 @@ def main():
                 entry['cpu_baseline'] = config_bench.cpu_baseline(name)
             result['configs'][name] = entry
     if comm.active:
-        comm.barrier()                                   # the ranks stay together until rank 0's CPU sample starts
+        comm.barrier()                                   # every timed region of every rank is over
+    D.synchronize()
+    parallel.shutdown()                                  # all ranks leave the group HERE: no collective (and no busy-waiting
+    #                                                      barrier kernel) is outstanding while rank 0 samples the CPU below
     if rank == 0 and not args.no_cpu_baseline:
         result['cpu_baseline'] = cpu_baseline(args, params)      # rank 0's host cores, after every timed region, any N
+        if world > 1:
+            result['cpu_baseline']['cores'] = len(os.sched_getaffinity(0))     # the rank is bound to its GPU's NUMA node
     if rank == 0:
         print(json.dumps(result))
-    if comm.active:
-        comm.barrier()                                   # nobody tears the communicator down under rank 0's feet
-    parallel.shutdown()
 
 
 if __name__ == '__main__':

@@ -44,13 +44,19 @@ int npm_comm_wait(void);
  * events on the communication stream and every npm_comm_wait by timing events on the compute stream;
  * npm_comm_stats synchronises both streams, returns the sums since the previous call and resets them.
  *   allreduce_ms  time the collectives occupied the communication stream (they overlap backward)
- *   exposed_ms    time the compute stream stood still in npm_comm_wait: what the exchange COSTS the step */
+ *   exposed_ms    time the compute stream stood still in npm_comm_wait: what the exchange COSTS the step
+ *   last_allreduce_ms  duration of the NEWEST all-reduce at each wait, summed: the flush a backward issues after its last
+ *                 gradient exists, which no computation is left to hide (the earlier flushes overlap the rest of backward)
+ * At most 8192 spans wait to be read; beyond that further ones are counted in `dropped` instead of recorded, and
+ * npm_comm_stats_enable(0) returns every pending event to the pool. */
 typedef struct npm_comm_exchange_stats {
     unsigned long long bytes;      /* payload bytes handed to ncclAllReduce */
     int allreduce_calls;
     int waits;
     double allreduce_ms;
     double exposed_ms;
+    double last_allreduce_ms;
+    int dropped;
 } npm_comm_exchange_stats;
 int npm_comm_stats_enable(int on);
 int npm_comm_stats(npm_comm_exchange_stats *out);

@@ -72,7 +72,8 @@ class npm_mha_core(C.Structure):
 
 class npm_comm_exchange_stats(C.Structure):
     _fields_ = [('bytes', C.c_ulonglong), ('allreduce_calls', C.c_int), ('waits', C.c_int),
-                ('allreduce_ms', C.c_double), ('exposed_ms', C.c_double)]
+                ('allreduce_ms', C.c_double), ('exposed_ms', C.c_double), ('last_allreduce_ms', C.c_double),
+                ('dropped', C.c_int)]
 
 
 EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK, EPI_RELU, EPI_SOFTMAX_BWD = 1, 2, 4, 8, 16, 32

@@ -55,10 +55,24 @@ struct Comm {
     bool stats = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> reduce_spans;   // on the communication stream, around each all-reduce
     std::vector<std::pair<hipEvent_t, hipEvent_t>> wait_spans;     // on the compute stream, around each wait
+    std::vector<size_t> last_before_wait;                          // index into reduce_spans of the newest all-reduce at each wait
     std::vector<hipEvent_t> spare;
     unsigned long long bytes = 0;
-    int calls = 0, waits = 0;
+    int calls = 0, waits = 0, dropped = 0;
 } g;
+
+// Spans wait for npm_comm_stats to read them; a caller that enables the statistics and never reads them must not grow
+// the event pool without bound: beyond this many pending spans further ones are counted (`dropped`), not recorded.
+constexpr size_t kMaxPendingSpans = 8192;
+
+// every pending span back to the spare list (the streams are idle: their events have completed)
+void recycle_spans() {
+    for (auto &span : g.reduce_spans) { g.spare.push_back(span.first); g.spare.push_back(span.second); }
+    for (auto &span : g.wait_spans) { g.spare.push_back(span.first); g.spare.push_back(span.second); }
+    g.reduce_spans.clear();
+    g.wait_spans.clear();
+    g.last_before_wait.clear();
+}
 
 int timed_event(hipEvent_t *ev) {
     if (!g.spare.empty()) {
@@ -154,13 +168,15 @@ int npm_comm_allreduce_f32(float *buf, size_t count, int op) {
     HIPC(hipEventRecord(g.produced, g.compute));          // gradients written so far ...
     HIPC(hipStreamWaitEvent(g.stream, g.produced, 0));    // ... are visible to the collective
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (g.stats) {
+    const bool timed = g.stats && g.reduce_spans.size() < kMaxPendingSpans;
+    if (g.stats && !timed) g.dropped += 1;
+    if (timed) {
         HIPC((hipError_t)timed_event(&t0));
         HIPC((hipError_t)timed_event(&t1));
         HIPC(hipEventRecord(t0, g.stream));
     }
     NCCLC(ncclAllReduce(buf, buf, count, ncclFloat32, to_op(op), g.comm, g.stream));
-    if (g.stats) {
+    if (timed) {
         HIPC(hipEventRecord(t1, g.stream));
         g.reduce_spans.emplace_back(t0, t1);
         g.bytes += (unsigned long long)count * sizeof(float);
@@ -183,22 +199,35 @@ int npm_comm_wait(void) {
     REQUIRE_READY();
     HIPC(hipEventRecord(g.reduced, g.stream));
     hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (g.stats) {
+    const bool timed = g.stats && g.wait_spans.size() < kMaxPendingSpans;
+    if (g.stats && !timed) g.dropped += 1;
+    if (timed) {
         HIPC((hipError_t)timed_event(&t0));
         HIPC((hipError_t)timed_event(&t1));
         HIPC(hipEventRecord(t0, g.compute));              // the compute stream arrives here ...
     }
     HIPC(hipStreamWaitEvent(g.compute, g.reduced, 0));
-    if (g.stats) {
+    if (timed) {
         HIPC(hipEventRecord(t1, g.compute));              // ... and goes on here: the difference is EXPOSED exchange time
         g.wait_spans.emplace_back(t0, t1);
         g.waits += 1;
+        // the newest all-reduce at this wait is the one nothing can overlap (a backward issues it after its last
+        // gradient): its duration is reported separately (last_allreduce_ms)
+        if (!g.reduce_spans.empty() && (g.last_before_wait.empty() || g.last_before_wait.back() != g.reduce_spans.size() - 1))
+            g.last_before_wait.push_back(g.reduce_spans.size() - 1);
     }
     return 0;
 }
 
 int npm_comm_stats_enable(int on) {
     REQUIRE_READY();
+    if (!on && g.stats) {                                 // nobody will read what is pending: give the events back
+        HIPC(hipStreamSynchronize(g.stream));
+        HIPC(hipStreamSynchronize(g.compute));
+        recycle_spans();
+        g.bytes = 0;
+        g.calls = g.waits = g.dropped = 0;
+    }
     g.stats = on != 0;
     return 0;
 }
@@ -208,30 +237,32 @@ int npm_comm_stats(npm_comm_exchange_stats *out) {
     if (!out) return fail(-1, "npm_comm_stats: null result");
     HIPC(hipStreamSynchronize(g.stream));
     HIPC(hipStreamSynchronize(g.compute));
-    double reduce_ms = 0, exposed_ms = 0;
+    double reduce_ms = 0, exposed_ms = 0, last_ms = 0;
     for (auto &span : g.reduce_spans) {
         float ms = 0;
         HIPC(hipEventElapsedTime(&ms, span.first, span.second));
         reduce_ms += ms;
-        g.spare.push_back(span.first);
-        g.spare.push_back(span.second);
+    }
+    for (size_t idx : g.last_before_wait) {
+        float ms = 0;
+        HIPC(hipEventElapsedTime(&ms, g.reduce_spans[idx].first, g.reduce_spans[idx].second));
+        last_ms += ms;
     }
     for (auto &span : g.wait_spans) {
         float ms = 0;
         HIPC(hipEventElapsedTime(&ms, span.first, span.second));
         exposed_ms += ms;
-        g.spare.push_back(span.first);
-        g.spare.push_back(span.second);
     }
     out->bytes = g.bytes;
     out->allreduce_calls = g.calls;
     out->waits = g.waits;
     out->allreduce_ms = reduce_ms;
     out->exposed_ms = exposed_ms;
-    g.reduce_spans.clear();
-    g.wait_spans.clear();
+    out->last_allreduce_ms = last_ms;
+    out->dropped = g.dropped;
+    recycle_spans();
     g.bytes = 0;
-    g.calls = g.waits = 0;
+    g.calls = g.waits = g.dropped = 0;
     return 0;
 }
 

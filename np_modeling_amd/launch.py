@@ -36,14 +36,100 @@ class _Terminated(Exception):
         self.signum = signum
 
 
-def _die_with_parent() -> None:
-    """Child side, between fork and exec: PR_SET_PDEATHSIG(SIGTERM) -- the kernel signals the rank when the launcher
-    thread that started it exits, however it exits (the clean-up of a SIGKILLed launcher)."""
-    import ctypes
+_HANDLED = (signal.SIGTERM, signal.SIGHUP)
+_PRCTL = None           # libc's prctl, resolved ONCE in the parent: the forked child only calls it
+
+
+def _resolve_prctl():
+    global _PRCTL
+    if _PRCTL is None:
+        import ctypes
+        try:
+            _PRCTL = ctypes.CDLL(None, use_errno=True).prctl
+        except (OSError, AttributeError):
+            _PRCTL = False
+    return _PRCTL
+
+
+def die_with_parent() -> bool:
+    """PR_SET_PDEATHSIG(SIGTERM): the kernel signals this process when the thread that started it exits, however it
+    exits (the clean-up of a SIGKILLed launcher).  Called between fork and exec by the launcher (with a function that
+    was bound before the fork: no import, no dlopen in the child) and once more by every rank at start-up
+    (np_modeling_amd/parallel.py init), which also covers a failure of the first call."""
+    prctl = _PRCTL if _PRCTL is not None else _resolve_prctl()
+    return bool(prctl) and prctl(1, int(signal.SIGTERM), 0, 0, 0) == 0            # PR_SET_PDEATHSIG = 1
+
+
+def _child_setup() -> None:
+    """Between fork and exec.  The launcher blocks its handled signals around each spawn (a signal must find every
+    started rank in its list); the block is inherited across exec, so the child lifts it again."""
+    signal.pthread_sigmask(signal.SIG_UNBLOCK, _HANDLED)
+    die_with_parent()
+
+
+# ---- NUMA placement ---------------------------------------------------------------------------------------------
+def _parse_cpulist(text: str) -> set:
+    cpus = set()
+    for part in text.strip().split(','):
+        if not part:
+            continue
+        lo, _, hi = part.partition('-')
+        cpus.update(range(int(lo), int(hi or lo) + 1))
+    return cpus
+
+
+def gpu_local_cpus(local_rank: int, sysfs: str = '/sys') -> Optional[set]:
+    """The CPUs of the NUMA node the ``local_rank``-th visible GPU hangs off, from sysfs alone (no HIP call):
+    the KFD topology lists the GPUs in the order HIP numbers them (nodes with simd_count > 0); ``location_id`` /
+    ``domain`` give the PCI address, whose ``local_cpulist`` the kernel provides.  HIP_VISIBLE_DEVICES /
+    ROCR_VISIBLE_DEVICES given as a plain list of indices are honoured.  None when anything is missing."""
     try:
-        ctypes.CDLL(None, use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG = 1
-    except Exception:
-        pass
+        nodes_dir = os.path.join(sysfs, 'class', 'kfd', 'kfd', 'topology', 'nodes')
+        gpus = []
+        for name in sorted(os.listdir(nodes_dir), key=int):
+            props = {}
+            with open(os.path.join(nodes_dir, name, 'properties')) as f:
+                for line in f:
+                    key, _, value = line.strip().partition(' ')
+                    props[key] = value
+            if int(props.get('simd_count', '0')) > 0:
+                gpus.append(props)
+        for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES'):
+            mask = os.environ.get(var)
+            if mask:
+                gpus = [gpus[int(i)] for i in mask.split(',')]
+        # np_modeling_amd/_C.py pick_device: NPM_DEVICE wins; a per-rank mask that leaves one device makes it device 0
+        index = int(os.environ['NPM_DEVICE']) if os.environ.get('NPM_DEVICE') else (0 if len(gpus) == 1 else local_rank)
+        props = gpus[index]
+        loc, domain = int(props['location_id']), int(props.get('domain', '0'))
+        bdf = f'{domain:04x}:{(loc >> 8) & 0xff:02x}:{(loc >> 3) & 0x1f:02x}.{loc & 7}'
+        with open(os.path.join(sysfs, 'bus', 'pci', 'devices', bdf, 'local_cpulist')) as f:
+            return _parse_cpulist(f.read()) or None
+    except (OSError, ValueError, IndexError, KeyError):
+        return None
+
+
+def bind_to_gpu_cpus(local_rank: int, sysfs: str = '/sys') -> dict:
+    """Restrict this process (before it starts any thread or touches the GPU) to the CPUs local to its GPU, so its host
+    thread, the driver's helper threads and its pinned buffers stay on the socket the card hangs off.  Returns what was
+    done, for bench.py's ``exchange`` object.  NPM_BIND_CPUS=0 switches it off."""
+    info = {'bound': False, 'local_rank': local_rank}
+    if os.environ.get('NPM_BIND_CPUS', '1') == '0' or not hasattr(os, 'sched_setaffinity'):
+        info['reason'] = 'disabled'
+        return info
+    allowed = os.sched_getaffinity(0)
+    local = gpu_local_cpus(local_rank, sysfs)
+    if not local:
+        info['reason'] = 'no NUMA information for this GPU in sysfs'
+        return info
+    cpus = local & allowed
+    if not cpus or cpus == allowed:
+        info['reason'] = 'the GPU-local CPUs are the whole affinity mask already' if cpus else 'the GPU-local CPUs are outside the affinity mask'
+        info['cpus'] = len(allowed)
+        return info
+    os.sched_setaffinity(0, cpus)
+    info.update(bound=True, cpus=len(cpus), first_cpu=min(cpus), last_cpu=max(cpus))
+    return info
 
 
 def rank_environment(rank: int, world: int, rendezvous_file: str, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
@@ -75,7 +161,8 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
     def on_signal(signum, frame):
         raise _Terminated(signum)
 
-    handled = (signal.SIGTERM, signal.SIGHUP)
+    handled = _HANDLED
+    _resolve_prctl()
     previous = {}
     try:
         for sig in handled:
@@ -84,8 +171,15 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
         previous = {}
     try:
         for rank in range(n):
-            procs.append(subprocess.Popen(list(argv), env=rank_environment(rank, n, rendezvous, env),
-                                          stdout=None if rank == 0 else sys.stderr, preexec_fn=_die_with_parent))
+            # a handled signal that arrives while Popen runs would raise out of it and leave a child that is in no
+            # list: hold it until the child is recorded (the child lifts the inherited block, _child_setup)
+            blocked = signal.pthread_sigmask(signal.SIG_BLOCK, handled) if previous else None
+            try:
+                procs.append(subprocess.Popen(list(argv), env=rank_environment(rank, n, rendezvous, env),
+                                              stdout=None if rank == 0 else sys.stderr, preexec_fn=_child_setup))
+            finally:
+                if blocked is not None:
+                    signal.pthread_sigmask(signal.SIG_SETMASK, blocked)
         pending = set(range(n))
         while pending and code == 0:
             for rank in sorted(pending):

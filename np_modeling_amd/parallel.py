@@ -114,7 +114,8 @@ class RcclCommunicator(Communicator):
         out = _C.npm_comm_exchange_stats()
         _C.check_comm(self._lib.npm_comm_stats(C.byref(out)), 'npm_comm_stats')
         return {'bytes': int(out.bytes), 'allreduce_calls': out.allreduce_calls, 'waits': out.waits,
-                'allreduce_ms': out.allreduce_ms, 'exposed_ms': out.exposed_ms}
+                'allreduce_ms': out.allreduce_ms, 'exposed_ms': out.exposed_ms,
+                'last_allreduce_ms': out.last_allreduce_ms, 'dropped': out.dropped}
 
     def close(self):
         self._lib.npm_comm_destroy()
@@ -122,6 +123,7 @@ class RcclCommunicator(Communicator):
 
 _COMM: Optional[Communicator] = None
 _REDUCE_OP = AVG
+PLACEMENT: dict = {'bound': False, 'reason': 'single process'}      # what init() did about CPU affinity (launch.bind_to_gpu_cpus)
 
 
 def _launch_token() -> str:
@@ -133,6 +135,13 @@ def _launch_token() -> str:
     explicit = os.environ.get('NPM_LAUNCH_TOKEN')
     if explicit:
         return explicit
+    if os.environ.get('NPM_RENDEZVOUS_FILE'):
+        # An explicitly named file may be shared by ranks that are NOT siblings (a second node on a shared file system,
+        # ranks started from separate shells): the token must not depend on the parent process.  The rendezvous address
+        # every rank of a job agrees on takes its place; a file left at the same name by an EARLIER job with the same
+        # address is not told apart by this token -- set NPM_LAUNCH_TOKEN to a per-job value where that can happen.
+        return (f'explicit-{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}-'
+                f'{os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")}')
     ppid = os.getppid()
     try:
         with open(f'/proc/{ppid}/stat') as f:
@@ -201,7 +210,9 @@ def _exchange_unique_id(rank: int, world_size: int, timeout: float = 300.0) -> b
     if local_world and int(local_world) != world_size and not os.environ.get('NPM_RENDEZVOUS_FILE'):
         raise _C.NpmError(f'WORLD_SIZE={world_size} but LOCAL_WORLD_SIZE={local_world}: the RCCL id travels through a '
                           'file of ONE node (SURVEY.md 8e: the 8 GPUs of a node); for several nodes put '
-                          'NPM_RENDEZVOUS_FILE on a file system all of them share')
+                          'NPM_RENDEZVOUS_FILE on a file system all of them share (and give every rank the same '
+                          'MASTER_ADDR / MASTER_PORT, or one NPM_LAUNCH_TOKEN per job: the file carries that token and ranks '
+                          'accept only a file with theirs)')
     path = rendezvous_path()
     if rank == 0:
         uid = RcclCommunicator.new_unique_id()
@@ -230,7 +241,8 @@ def _exchange_unique_id(rank: int, world_size: int, timeout: float = 300.0) -> b
             what = 'only a file of another launch' if seen_foreign else 'no file'
             raise _C.NpmError(f'rank {rank}: no RCCL id from rank 0 at {path} after {timeout:.0f} s ({what}); '
                               f'launch token {_launch_token()!r}. Ranks must be children of one launcher process on one '
-                              'node (or share NPM_LAUNCH_TOKEN and NPM_RENDEZVOUS_FILE)')
+                              'node, or share an explicit NPM_RENDEZVOUS_FILE together with the same MASTER_ADDR / MASTER_PORT '
+                              '(or the same NPM_LAUNCH_TOKEN)')
         time.sleep(0.01)
 
 
@@ -245,6 +257,16 @@ def init(reduce: str = 'avg') -> Communicator:
     if world <= 1 and os.environ.get('NPM_FORCE_RCCL', '0') != '1':
         _COMM = Communicator()
         return _COMM
+    global PLACEMENT
+    if world > 1:
+        # one rank of several on this node: die with the launcher, and run on the CPUs of the GPU's own NUMA node --
+        # both before anything touches the device (the driver's threads inherit the mask)
+        from np_modeling_amd import launch
+        launch.die_with_parent()
+        if _C._LIB is None:
+            PLACEMENT = launch.bind_to_gpu_cpus(int(os.environ.get('LOCAL_RANK', str(rank))))
+        else:
+            PLACEMENT = {'bound': False, 'reason': 'the device library was loaded before parallel.init()'}
     _C.lib()                                             # bind this process to cuda:LOCAL_RANK first
     uid = _exchange_unique_id(rank, world) if world > 1 else RcclCommunicator.new_unique_id()
     _COMM = RcclCommunicator(rank, world, uid)

@@ -640,3 +640,61 @@ def test_terminated_launcher_takes_its_ranks_along(tmp_path):
         while not all(gone(pid) for pid in pids) and time.monotonic() < deadline:
             time.sleep(0.05)
         assert all(gone(pid) for pid in pids), f'ranks survived a launcher ended by signal {sig}: {pids}'
+
+
+def test_gpu_local_cpus_from_a_fake_sysfs(tmp_path, monkeypatch):
+    """launch.gpu_local_cpus / bind_to_gpu_cpus: KFD topology order -> PCI address -> local_cpulist, per-rank device masks,
+    and the affinity call itself (on whatever CPUs this test may use)."""
+    from np_modeling_amd import launch
+    for var in ('ROCR_VISIBLE_DEVICES', 'HIP_VISIBLE_DEVICES', 'NPM_DEVICE', 'NPM_BIND_CPUS'):
+        monkeypatch.delenv(var, raising=False)
+    allowed = sorted(os.sched_getaffinity(0))
+    half = allowed[:max(1, len(allowed) // 2)]
+    lists = {0: '0-3,8', 1: ','.join(str(c) for c in half)}
+    nodes = tmp_path / 'class' / 'kfd' / 'kfd' / 'topology' / 'nodes'
+    # node 0 is a CPU (simd_count 0); nodes 1 and 2 are GPUs at 0000:05:00.0 and 0001:c3:00.0
+    for node, (simd, loc, dom) in enumerate([(0, 0, 0), (1024, 0x0500, 0), (1024, 0xc300, 1)]):
+        d = nodes / str(node)
+        d.mkdir(parents=True)
+        (d / 'properties').write_text(f'cpu_cores_count 0\nsimd_count {simd}\nlocation_id {loc}\ndomain {dom}\n')
+    for gpu, bdf in enumerate(['0000:05:00.0', '0001:c3:00.0']):
+        d = tmp_path / 'bus' / 'pci' / 'devices' / bdf
+        d.mkdir(parents=True)
+        (d / 'local_cpulist').write_text(lists[gpu] + '\n')
+    root = str(tmp_path)
+    assert launch.gpu_local_cpus(0, root) == {0, 1, 2, 3, 8}
+    assert launch.gpu_local_cpus(1, root) == set(half)
+    assert launch.gpu_local_cpus(2, root) is None                       # no such GPU
+    monkeypatch.setenv('HIP_VISIBLE_DEVICES', '1')                      # a per-rank mask: the one visible device is this rank's
+    assert launch.gpu_local_cpus(5, root) == set(half)
+    monkeypatch.delenv('HIP_VISIBLE_DEVICES')
+    assert launch.gpu_local_cpus(0, str(tmp_path / 'nothing')) is None
+    monkeypatch.setenv('NPM_BIND_CPUS', '0')
+    assert launch.bind_to_gpu_cpus(1, root) == {'bound': False, 'local_rank': 1, 'reason': 'disabled'}
+    monkeypatch.delenv('NPM_BIND_CPUS')
+    before = os.sched_getaffinity(0)
+    try:
+        info = launch.bind_to_gpu_cpus(1, root)
+        if len(allowed) > 1:
+            assert info['bound'] and info['cpus'] == len(half) and os.sched_getaffinity(0) == set(half)
+        else:
+            assert not info['bound']
+    finally:
+        os.sched_setaffinity(0, before)
+    assert launch.die_with_parent() is True                             # PR_SET_PDEATHSIG through the pre-bound prctl
+
+
+def test_explicit_rendezvous_file_shared_by_ranks_of_different_parents(tmp_path):
+    """Two ranks started by DIFFERENT parent processes (two shells, two nodes on a shared file system) that share an explicit
+    NPM_RENDEZVOUS_FILE and the same MASTER_ADDR / MASTER_PORT: the launch token of an explicit file does not depend on the
+    parent, so rank 1 accepts rank 0's id (round-3 advisor: it used to time out after 300 s)."""
+    env = dict(_clean_env(), NPM_RENDEZVOUS_FILE=str(tmp_path / 'shared_id'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29517',
+               WORLD_SIZE='2', LOCAL_WORLD_SIZE='1')
+    worker = os.path.join(ROOT, 'tests', 'uid_worker.py')
+    # each rank is the child of its own intermediate process
+    hop = 'import subprocess, sys; sys.exit(subprocess.call([sys.executable, sys.argv[1]]))'
+    procs = [subprocess.Popen([sys.executable, '-c', hop, worker], env=dict(env, RANK=str(r), LOCAL_RANK='0'), cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (1, 0)]
+    outs = [p.communicate(timeout=120)[0] for p in procs]
+    assert [p.returncode for p in procs] == [0, 0], outs
+    assert 'rank 1/2: id ok' in outs[0] and 'rank 0/2: id ok' in outs[1]

@@ -49,6 +49,6 @@ python3 profiles/summarize_pmc.py "$OUT"/pmc_FETCH_SIZE/*/*_counter_collection.c
 echo "== TCC request counters of the FFN weight-gradient GEMM (DRAM-destined vs all; L2 hit / miss)"
 tools/pmc/one_shape.sh "ffn_dw_TN M=1024" 10=0 "$OUT/pmc_tn" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RD_UNCACHED_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" > "$OUT/${R}_pmc_tcc_ffn_dw.log" 2>&1
 echo "== SQ counters: fused attention"
-tools/pmc/attn.sh "$OUT/pmc_attn" > "$OUT/${R}_pmc_attn_core.log" 2>&1
+tools/pmc/attn.sh "$OUT/pmc_attn" --save-scores > "$OUT/${R}_pmc_attn_core.log" 2>&1
 rm -rf "$OUT"/prof "$OUT"/prof_cfg "$OUT"/prof_dec "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_tn "$OUT"/pmc_attn
 echo "== done"; ls "$OUT"
