@@ -126,8 +126,9 @@ enum {
     NPM_TUNE_GEMM_MATH = 10,         /* same as npm_set_math */
     NPM_TUNE_ATTN_STAGGER = 11,      /* attention forward: s_sleep(127) units one of the two blocks of a CU waits at its start (default 1) */
     NPM_TUNE_CONV_WGRAD_FUSED = 13,  /* npm_conv2d_bwd_w_relu: 1 (default) ReLU backward inside the grad_w kernel, tile height picked; 2 / 3 the same with 128- / 192-row tiles; 0 two passes */
-    NPM_TUNE_ATTN_BWD16 = 14,        /* attention backward, head size 128, saved scores: 1 (default) the 8-wave 16x16x4-MFMA kernel (two waves per SIMD), 0 the 4-wave 32x32x2 one */
+    NPM_TUNE_ATTN_BWD16 = 14,        /* attention backward: 2 (default) mha_bwd8_kernel (8 waves on the 16x16x4 MFMA, one barrier per tile, every head size, both score modes, tile skipping) except head size 128 with saved scores and no tile summary, which runs mha_bwd16_kernel; 3 mha_bwd8_kernel always; 1 round 3's choice (mha_bwd16_kernel for head size 128 with saved scores, the 4-wave 32x32x2 kernel otherwise); 0 the 4-wave kernel always */
     NPM_TUNE_KSYNC = 15,             /* K tiles between the soft rendezvous of the co-resident split-K blocks of the fused Conv2D filter gradient: a power of two, default 128; 0 off */
+    NPM_TUNE_CONV_KORDER = 16,       /* Conv2D forward / grad_x K loop: 1 (default) the k k taps of one 16-channel chunk back to back (the lines a tap fetched are still in L2 when its neighbour wants them: grad_x of C3 reads 13.8 instead of 82 GB past the L2s, +4 %), 0 taps outermost (kk = tap C + c) */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
     NPM_TUNE_GEMM_ABLATE = 99
 };
@@ -249,10 +250,27 @@ typedef struct npm_mha_core {
     float *dq; int64_t dq_pitch;
     float *dk; int64_t dk_pitch;
     float *dv; int64_t dv_pitch;
+    /* Optional, with `mask`: the mask's tile summary from npm_mha_mask_summary -- one byte per (query tile of 32, key block
+     * of 128), bit w set when some position of the 32 x 16 sub-tile (keys 16 w .. 16 w + 15 of the block) is allowed; byte
+     * (qt, kb) of plane (b, h) at tile_summary[b * summary_stride_b + h * summary_stride_h + qt * ceil(seq_kv / 128) + kb]
+     * (a stride of 0 broadcasts, like the mask's).  Forward and backward then skip tiles without an allowed position: the
+     * results are the same as without it; positions of `scores` inside skipped tiles are left unwritten (the backward never
+     * reads them).  Used for seq_q, seq_kv <= 2048; longer sequences run unskipped. */
+    const uint8_t *tile_summary; int64_t summary_stride_b, summary_stride_h;
+    int64_t summary_all_offset;   /* bytes from a tile's "some position allowed" byte to its "every position allowed" byte (the second
+                                     half of what npm_mha_mask_summary writes: planes_b * planes_h * tiles bytes later); 0 = not given.
+                                     Tiles whose every position is allowed run without reading the mask. */
 } npm_mha_core;
 int npm_mha_core_supported(int head_dim);          /* 1 when npm_mha_core_fwd/bwd take this head dimension */
 int npm_mha_core_fwd(const npm_mha_core *c);
 int npm_mha_core_bwd(const npm_mha_core *c);
+/* summary[2][plane_b][plane_h][ceil(seq_q / 32)][ceil(seq_kv / 128)] (first the "some position allowed" bytes, then, in the
+ * same order, the "every position inside the tensors allowed" bytes) of a byte mask laid out like npm_mha_core's (element
+ * (b, h, i, j) at mask[b * stride_b + h * stride_h + i * stride_q + j]); planes_b / planes_h = how many distinct planes the
+ * mask has along batch and head (1 where it broadcasts).  np.where(mask, scaled, -inf) of attentions.py:105-107 skips
+ * nothing; this is what lets the fused kernels skip the tiles such a mask empties (half of a causal mask's). */
+int npm_mha_mask_summary(const uint8_t *mask, int64_t stride_b, int64_t stride_h, int64_t stride_q, int32_t planes_b,
+                         int32_t planes_h, int32_t seq_q, int32_t seq_kv, uint8_t *summary);
 /* Which kernel the most recent npm_mha_core_fwd / npm_mha_core_bwd call launched, as "<kernel> D=<head_dim> mask=<0|1>
  * scores=<0|1>" (e.g. "mha_bwd16_kernel D=128 mask=0 scores=1"); "" before the first call.  Tests use it to assert that
  * a comparison exercised the kernel it names. */

@@ -67,6 +67,8 @@ class npm_mha_core(C.Structure):
         ('dq', C.c_void_p), ('dq_pitch', C.c_int64),
         ('dk', C.c_void_p), ('dk_pitch', C.c_int64),
         ('dv', C.c_void_p), ('dv_pitch', C.c_int64),
+        ('tile_summary', C.c_void_p), ('summary_stride_b', C.c_int64), ('summary_stride_h', C.c_int64),
+        ('summary_all_offset', C.c_int64),
     ]
 
 
@@ -127,6 +129,7 @@ SIGNATURES = {
     'npm_mha_core_supported': [C.c_int],
     'npm_mha_core_fwd': [C.POINTER(npm_mha_core)],
     'npm_mha_core_bwd': [C.POINTER(npm_mha_core)],
+    'npm_mha_mask_summary': [_P, _I64, _I64, _I64, _I32, _I32, _I32, _I32, _P],
     'npm_adam_step': [_P, _P, _P, _P, _SZ, C.c_double, C.c_double, C.c_double, C.c_double, C.c_int],
     'npm_fill_f64': [_P, C.c_double, _SZ],
     'npm_mse_fwd': [_P, _P, _SZ, C.POINTER(C.c_double)],

@@ -38,7 +38,13 @@ struct MhaArgs {
     float *ctx;
     long ctx_pitch;
     float *lse;                       // [B, H, Sq]
-    float *delta;                     // backward scratch [B, H, Sq]: rowsum(dctx * ctx)
+    float *delta;                     // backward scratch [B, H, Sq]: rowsum(dctx * ctx) ([B, H, sq_pad] for mha_bwd8_kernel)
+    float *lse2;                      // mha_bwd8_kernel: [B, H, sq_pad] log2(e) * LSE, zeros in the padding
+    int sq_pad;                       // seq_q rounded up to whole 32-query tiles
+    const unsigned char *skip;        // optional tile summary (npm_mha_mask_summary): byte (qt, kb) at skip[b sb + h sh + qt nkb + kb]
+    long skip_sb, skip_sh;
+    int skip_nkb;
+    long skip_all;                    // byte offset from an "any" byte to the "all" byte of the same tile (0: no "all" bits)
     const float *dctx;
     long dctx_pitch;
     float *dq, *dk, *dv;
@@ -48,7 +54,8 @@ struct MhaArgs {
     float *scores;                    // optional [B, H, Sq, Skv]: raw (unscaled, masked) scores kept for the backward
     int batch, heads, seq_q, seq_kv;
     float scale;
-    int q_tiles;                      // forward: blocks per (b, h)
+    int q_tiles;                      // forward: 128-query tiles per (b, h)
+    int q_pair;                       // forward: 1 = a block takes the two tiles u and q_tiles - 1 - u (balanced work under a mask)
     int stagger;                      // forward: s_sleep(127) units one of the two blocks of a CU waits at its start
     long long *trace;                 // diagnostics (npm_debug_attn_trace): 16 s_memtime stamps per block, or null
 };
@@ -185,8 +192,21 @@ mha_fwd_kernel(const MhaArgs p) {
     const int l32 = lane & 31, half = lane >> 5;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int qt = logical % p.q_tiles, bh = logical / p.q_tiles;
+    // With a tile summary a block takes TWO query tiles, u and q_tiles - 1 - u, one after the other (p.q_pair): under a causal
+    // mask -- under any mask whose rows see more and more keys -- the work of a query tile grows with its index, blocks of 4 / 8 /
+    // 12 / 16 key tiles at C4's shape, and the dispatcher hands blocks to CUs in order: the light ones queue behind the heavy
+    // ones (2.07 ms, against 1.45 ms for a mask with the SAME number of visited tiles spread evenly).  Paired, every block has
+    // the same work.
+    const bool pairing = MASK && p.q_pair;                                   // (summaries come with masks: no loop in the unmasked instances)
+    const int units = pairing ? (p.q_tiles + 1) / 2 : p.q_tiles;
+    const int unit = logical % units, bh = logical / units;
     const int b = bh / p.heads, h = bh - b * p.heads;
+  for (int rep = 0; rep < (pairing ? 2 : 1); ++rep) {
+    const int qt = rep == 0 ? unit : p.q_tiles - 1 - unit;
+    if (rep == 1) {
+        if (qt == unit) break;                                               // odd count: the middle tile has no partner
+        __syncthreads();                                                     // every wave is done with the LDS stages of the first tile
+    }
     const int qrow = qt * 128 + wave * 32 + l32;                             // this lane's query
     const bool qok = qrow < p.seq_q;
 
@@ -229,6 +249,7 @@ mha_fwd_kernel(const MhaArgs p) {
     // first key in the scalar offset, the key inside the tile in the immediate; a key or query beyond the end reads 0 = masked
     const auto rsrcM = make_rsrc(MASK ? p.mask + b * p.mask_sb + h * p.mask_sh : nullptr, MASK ? (long)(p.seq_q - 1) * p.mask_sq + p.seq_kv : 0);
     const int mvoff = qok ? (int)(qrow * p.mask_sq + 4 * half) : OOB;
+    const bool mask_dw = MASK && (p.mask_sq & 3) == 0 && (p.seq_kv & 3) == 0 && ((unsigned long)(p.mask + b * p.mask_sb + h * p.mask_sh) & 3) == 0;
     // Saved scores of this (b, h): [seq_q][seq_kv] behind one descriptor.  A lane's part of the address (its query row,
     // its 4 half keys) is ONE register, the tile's first key a scalar offset, the register group an immediate: a full
     // tile is four bare buffer_store_dwordx4, rows beyond seq_q carry an out-of-range offset.
@@ -236,29 +257,63 @@ mha_fwd_kernel(const MhaArgs p) {
     const int svoff = qok ? (int)(((long)qrow * p.seq_kv + 4 * half) * 4) : OOB;
     const bool rows16 = (p.seq_kv & 3) == 0;             // every score row starts 16-byte aligned
 
-    issue(0, 0);
+    // Tile skipping (masks): bit t of `act` = some query of this block may look at key tile t, bit t of `mine` = some query
+    // of this wave may (p.skip: one byte per (query tile of 32, key block of 128), bit w = keys 16 w .. 16 w + 15 of the
+    // block; npm_mha_mask_summary).  Tiles outside `act` are not visited (no pieces, no barrier, nothing stored for them);
+    // in a visited tile a wave outside `mine` only takes part in the pieces and the barrier.
+    // `plain`: bit t = EVERY position of this wave's 32 queries x the 32 keys of tile t is allowed (the summary's "all" bits):
+    // such a tile needs no mask bytes and no compares -- under a causal mask all but one visited tile per wave.
+    unsigned long act = ~0ul, mine = ~0ul, plain = 0ul;
+    const bool skipping = MASK && p.skip != nullptr;
+    if (skipping) {
+        const unsigned char *sk = p.skip + b * p.skip_sb + h * p.skip_sh;
+        unsigned any = 0, own = 0, full = 0;
+        if (lane < nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qtile = 4 * qt + i;
+                const unsigned bits = qtile * 32 < p.seq_q ? (sk[(long)qtile * p.skip_nkb + (lane >> 2)] >> (2 * (lane & 3))) & 3u : 0u;
+                any |= bits;
+                if (i == wave) own = bits;
+            }
+            const int mytile = 4 * qt + wave;
+            if (p.skip_all && mytile * 32 < p.seq_q)
+                full = (sk[p.skip_all + (long)mytile * p.skip_nkb + (lane >> 2)] >> (2 * (lane & 3))) & 3u;
+        }
+        act = __builtin_amdgcn_ballot_w64(any != 0);
+        mine = __builtin_amdgcn_ballot_w64(own != 0);
+        plain = __builtin_amdgcn_ballot_w64(full == 3u);
+    }
+    const int t_first = skipping ? (act ? __builtin_ctzl(act) : -1) : 0;
+    if (t_first >= 0) issue(t_first, 0);
     // The two blocks of a CU run the same program; started together they reach their softmax (no MFMA) together and
     // the matrix pipe idles.  Blocks b and b + 256 share a CU on a first dispatch: delay one of them by about half a
     // tile, later generations inherit the offset.  (Placement is not guaranteed: this is for speed only.)
-    if (p.stagger && ((blockIdx.x >> 8) & 1)) {
+    if (p.stagger && rep == 0 && ((blockIdx.x >> 8) & 1)) {
         for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     }
     if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     // One key tile out of LDS stage STG.  The loop below is unrolled by two so that the stage is a compile-time constant: every
     // LDS address of the tile is a loop-invariant register plus an immediate (32 vector-ALU adds per tile fewer -- each costs the
     // matrix pipe its issue cycles, tools/microbench/mfma_f32_16x16.hip).
-    auto tile = [&](auto stage_c, const int t) __attribute__((always_inline)) {
+    auto tile = [&](auto stage_c, const int t, const int t_next) __attribute__((always_inline)) {
         constexpr int STG = decltype(stage_c)::value;
         npm_tile::dma_barrier();                        // tile t has landed (every wave's pieces); nobody still reads the stage refilled next
         long long *tr = (TRACE && p.trace && tid == 0 && t == (nt > 5 ? 5 : 0)) ? p.trace + (long)blockIdx.x * 16 : nullptr;
         if (TRACE && p.trace && tid == 0 && t == (nt > 5 ? 6 : 1)) { FENCE(); p.trace[(long)blockIdx.x * 16 + 4] = __builtin_amdgcn_s_memtime(); FENCE(); }
         STAMP(0);
-        if (t + 1 < nt) issue(t + 1, STG ^ 1);
+        if (t_next >= 0) issue(t_next, STG ^ 1);
+        if (skipping && !((mine >> t) & 1)) return;     // no query of this wave may look at these 32 keys
         const float *sK = smem + STG * TILE, *sV = smem + (2 + STG) * TILE;
-        unsigned char mk[16];
-        if (MASK) {                                     // requested now, used behind the 64 MFMAs of the score product
+        // Mask bytes of this tile: requested now, used behind the 64 MFMAs of the score product.  The four keys a register group
+        // holds are four ADJACENT bytes: one dword load per group (4 loads, 4 registers) when every row of the mask starts on a
+        // 4-byte boundary and no dword straddles the end; byte by byte (16 loads, issued late: the register file has no room for
+        // 16 more live values across the score product at D = 128) otherwise.
+        unsigned mkw[4];
+        const bool masked_tile = MASK && !((plain >> t) & 1);     // (plain is 0 without a summary: every tile reads its mask)
+        if (masked_tile && mask_dw) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) mk[r] = __builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff + (r & 3) + 8 * (r >> 2), 32 * t, 0);
+            for (int g4 = 0; g4 < 4; ++g4) mkw[g4] = __builtin_amdgcn_raw_buffer_load_b32(rsrcM, mvoff + 8 * g4, 32 * t, 0);
         }
 
         // ---- S^T[kv, q] = K Q^T: NG steps of (1 row read, 4 MFMAs), every read one step ahead of its use
@@ -289,10 +344,19 @@ mha_fwd_kernel(const MhaArgs p) {
             for (int r = 0; r < 16; ++r)
                 if (kv0 + (r & 3) + 8 * (r >> 2) >= p.seq_kv) S[r] = -INFINITY;
         }
-        if (MASK) {
+        if (masked_tile) {
+            if (!mask_dw) {
+#pragma unroll
+                for (int g4 = 0; g4 < 4; ++g4) {
+                    mkw[g4] = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        mkw[g4] |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff + e + 8 * g4, 32 * t, 0) << (8 * e);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                if (mk[r] == 0) S[r] = -INFINITY;
+                if (((mkw[r >> 2] >> (8 * (r & 3))) & 0xffu) == 0) S[r] = -INFINITY;
         }
         if (SAVE) {
             const int stile = 32 * t * 4;                                     // scalar: byte offset of the tile's first key
@@ -357,9 +421,18 @@ mha_fwd_kernel(const MhaArgs p) {
         }
         STAMP(3);
     };
-    for (int t = 0; t < nt; t += 2) {
-        tile(std::integral_constant<int, 0>{}, t);
-        if (t + 1 < nt) tile(std::integral_constant<int, 1>{}, t + 1);
+    auto next_tile = [&](int t) -> int {               // the tile visited after tile t, or -1
+        if (!skipping) return t + 1 < nt ? t + 1 : -1;
+        const unsigned long m = t < 63 ? act >> (t + 1) : 0ul;
+        return m ? t + 1 + __builtin_ctzl(m) : -1;
+    };
+    for (int t = t_first; t >= 0;) {
+        const int t1 = next_tile(t);
+        tile(std::integral_constant<int, 0>{}, t, t1);
+        if (t1 < 0) break;
+        const int t2 = next_tile(t1);
+        tile(std::integral_constant<int, 1>{}, t1, t2);
+        t = t2;
     }
     if (blk_tr) blk_tr[12] = __builtin_amdgcn_s_memtime();
 
@@ -383,6 +456,7 @@ mha_fwd_kernel(const MhaArgs p) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         blk_tr[13] = __builtin_amdgcn_s_memtime();
     }
+  }   // rep
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1020,9 +1094,460 @@ mha_bwd16_kernel(const MhaArgs p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Backward, round 4: EIGHT wavefronts on v_mfma_f32_16x16x4_f32 for EVERY head size and both score modes, ONE workgroup
+// barrier per tile, tiles without an allowed position skipped.
+//
+// mha_bwd16_kernel above (head size 128, saved scores) spends 17.6 % of its wave cycles in s_waitcnt / s_barrier and keeps
+// the matrix pipe 82 % busy (profiles/r04_pmc_attn_sq.log): two barriers per tile -- "the tile has landed" at the top and "dS of
+// all eight key groups is in LDS" in front of the dQ product -- and at each of them both waves of a SIMD stand still together.
+// Here the dQ product of tile j runs at the START of tile j + 1 (software pipelining across tiles: two dS buffers), so the one
+// barrier at the top of a tile says both things.  LDS at D = 128: K block 64 KB + two Q and two dO stages 64 KB + two dS tiles
+// 32 KB = 160 KB exactly; the row terms no longer pass through LDS (mha_rowterms_kernel stores log2(e) LSE and delta padded to
+// whole tiles, and a lane's four consecutive queries are ONE 16-byte buffer load each).
+//
+// Operand layouts as in mha_bwd16_kernel (lane l: l16 = l & 15, kk = l >> 4), generalised over NC = D / 16:
+//   S[q, kv]    = Q K^T (recomputing mode): A = row q of the Q tile, 16 bytes at d = 16 c + 4 kk; B = the wave's own key row
+//                 of the K block at the same d
+//   dP[q, kv]   = dO V^T: A = row q of the dO tile; B = the V fragment in registers (scaled by 1 / sqrt(Dk))
+//   dV^T / dK^T : A = VW = min(4, D / 16) adjacent head dimensions of row q = 16 t + 4 kk + r of the dO / Q tile (element e
+//                 belongs to d-tile e), B = P[t][r] / dS[t][r]
+//   dQ^T[d, q]  : wave w takes d-slice w % NC (and, for NC < 8, query half w / NC; waves >= 2 NC have no slice)
+// Last tile of a key block: its dQ product cannot wait for the next tile (the K block is replaced), so that tile keeps the
+// two-barrier form and the next K block / V fragment are requested in front of its dK product, as before.
+//
+// Tile skipping (masks): p.skip holds one byte per (query tile of 32, key block of 128) whose bit w says "some position of
+// the 32 x 16 sub-tile of wave w is allowed" (npm_mha_mask_summary).  A tile whose byte is 0 is not visited at all, a wave
+// whose bit is 0 skips its S / dP / dV / dK products (its dS columns are zeros).  Saved scores of skipped tiles are never
+// read (the forward does not write them).  dQ rows of tiles no key block visits are zero-filled at the end.
+//
+// Hand-counted waits (checked against the disassembly by tools/waitcnt_check.py): the LDS-DMA pieces are issued from
+// inline assembly and are invisible to the compiler; the wait at the top of a tile is `s_waitcnt vmcnt(N)` with N = the
+// number of vector-memory instructions this wave issued AFTER its last piece: the 2 NC dK / dV stores of a key-block seam
+// (the K block's pieces and the V fragment's loads are older than those), else 0.  The Q / dO pieces of the next tile are
+// issued in the dV product, BEHIND every compiler-visible load of the tile (row terms, scores, mask bytes, old dQ).
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool MASK, bool SAVED>
+__global__ void __launch_bounds__(512, D == 16 ? 4 : 2)      // (waves per SIMD) D = 16: 48 KB of LDS, two blocks per CU: 128 registers per wave
+mha_bwd8_kernel(const MhaArgs p) {
+    using T = Tile<D>;
+    using TS = Tile<128>;
+    constexpr int NC = D / 16;
+    constexpr int QTILE = 32 * D, KBLK = 128 * D, ROWS16 = 16 * D, SROWS16 = 16 * 128, DSBUF = 32 * 128;   // floats
+    constexpr int QP = D / 8, QPPW = QP >= 8 ? QP / 8 : 1, KPPW = D / 16;        // 1 KiB DMA pieces: Q / dO tile, per wave; K block per wave
+    constexpr int VW = D >= 64 ? 4 : D / 16, NV = NC / VW;                       // column-vector reads: width, reads per step
+    constexpr int DQT = NC == 8 ? 2 : 1;                                         // query halves a wave's dQ slice covers
+    constexpr int NB = NC < 4 ? NC : 4;
+    constexpr bool CTP = D < 128;                                                // compile-time stage / buffer parity (see `visit`)
+    static_assert(!(MASK && SAVED), "saved scores carry the mask");
+    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + 2 * DSBUF];
+    float *const sKB = smem, *const sQ = sKB + KBLK, *const sDO = sQ + 2 * QTILE, *const sDS = sDO + 2 * QTILE;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0 .. 7
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int bh = blockIdx.x;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+
+    const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
+    const auto descQ = make_desc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
+    const auto descDO = make_desc(p.dctx + (long)b * p.seq_q * p.dctx_pitch + h * D, ((long)(p.seq_q - 1) * p.dctx_pitch + D) * 4);
+    const auto rsrcDQ = make_rsrc(p.dq + (long)b * p.seq_q * p.dq_pitch + h * D, ((long)(p.seq_q - 1) * p.dq_pitch + D) * 4);
+    const auto rsrcDK = make_rsrc(p.dk + (long)b * p.seq_kv * p.dk_pitch + h * D, ((long)(p.seq_kv - 1) * p.dk_pitch + D) * 4);
+    const auto rsrcDV = make_rsrc(p.dv + (long)b * p.seq_kv * p.dv_pitch + h * D, ((long)(p.seq_kv - 1) * p.dv_pitch + D) * 4);
+    const auto rsrcNone = make_rsrc(p.dq, 0);
+    // row terms, padded to whole tiles and finite in the padding (mha_rowterms_kernel): no straddling 16-byte load
+    const auto rsrcL = make_rsrc(p.lse2 + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
+    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
+    const auto rsrcS = make_rsrc(SAVED ? p.scores + (long)bh * p.seq_q * p.seq_kv : nullptr, SAVED ? (long)p.seq_q * p.seq_kv * 4 : 0);
+    const int srow_bytes = p.seq_kv * 4;
+    const auto rsrcM = make_rsrc(MASK ? p.mask + b * p.mask_sb + h * p.mask_sh : nullptr, MASK ? (long)(p.seq_q - 1) * p.mask_sq + p.seq_kv : 0);
+
+    // ---- LDS-DMA lane offsets
+    unsigned vq[QPPW], vdo[QPPW], vkb[KPPW];
+#pragma unroll
+    for (int i = 0; i < QPPW; ++i) {
+        vq[i] = T::src(lane, wave * QPPW + i, p.q_pitch);
+        vdo[i] = T::src(lane, wave * QPPW + i, p.dctx_pitch);
+    }
+#pragma unroll
+    for (int i = 0; i < KPPW; ++i) vkb[i] = T::src(lane, wave * KPPW + i, p.k_pitch);
+    const bool q_owner = QP >= 8 || wave < QP;                                  // D < 64: the tile has fewer pieces than waves
+    const unsigned qstep = (unsigned)(32 * p.q_pitch * 4), dostep = (unsigned)(32 * p.dctx_pitch * 4);
+    const unsigned lds_q = lds_offset(sQ + wave * QPPW * 256), lds_do = lds_offset(sDO + wave * QPPW * 256), lds_kb = lds_offset(sKB + wave * KPPW * 256);
+    auto issue_q = [&](int qt, int stage) { if (q_owner) dma_group<QPPW>(descQ, lds_q + stage * QTILE * 4, (unsigned)qt * qstep, vq); };
+    auto issue_do = [&](int qt, int stage) { if (q_owner) dma_group<QPPW>(descDO, lds_do + stage * QTILE * 4, (unsigned)qt * dostep, vdo); };
+
+    // ---- LDS addresses (floats): lane-dependent bases, everything else an immediate
+    int rb[NB], vb[4], rbS[4], wsS[4], wsK[4];
+    const int dqs = NC == 8 ? wave : wave % NC;                                 // d-slice of this wave's dQ rows
+    const int dqh = NC == 8 ? 0 : wave / NC;                                    // ... and (NC < 8) its query half
+    const bool dq_wave = NC == 8 || wave < 2 * NC;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = T::chunk(l16, 4 * j + kk);             // rows 16 t + l16, chunk 4 c + kk: + t ROWS16 + (c >> 2) 64
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        vb[j] = T::elem(4 * kk + j, VW * l16);                                  // column vectors: row 16 t + 4 kk + r; + t ROWS16 (+ 64)
+        rbS[j] = TS::chunk(l16, 4 * j + kk);                                    // dS tile rows 16 t + l16; + t SROWS16 + (c >> 2) 64
+        wsS[j] = TS::elem(4 * kk + j, 16 * wave + l16);                         // dS elements: row 16 t + 4 kk + r, this lane's key
+        wsK[j] = T::elem(4 * kk + j, 16 * dqs + l16);                           // K block: row 16 c + 4 kk + s, column of the dQ slice
+    }
+    const float *const sKW = sKB + 16 * wave * D;                               // this wave's 16 key rows
+
+    const float c = p.scale * LOG2E;
+    const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
+    const int kvl = 16 * wave + l16;
+    const int dq_voff = (int)((l16 * p.dq_pitch + 16 * dqs + 4 * kk) * 4);
+    const int dq_sub = 16 * (int)p.dq_pitch * 4;
+
+    // ---- which tiles exist
+    const unsigned char *const sk = p.skip ? p.skip + b * p.skip_sb + h * p.skip_sh : nullptr;
+    auto load_tiles = [&](int kb, int &bytes) -> unsigned long {                // bit qt: tile (qt, kb) is visited
+        if (!sk) return ~0ul;
+        bytes = lane < nqt ? (int)sk[(long)lane * p.skip_nkb + kb] : 0;
+        if (MASK && p.skip_all && lane < nqt) bytes |= (int)sk[p.skip_all + (long)lane * p.skip_nkb + kb] << 8;   // bits 8..15: "all"
+        const unsigned long any = __builtin_amdgcn_ballot_w64((bytes & 0xff) != 0);
+        return any ? any : 1ul;                                                 // an empty key block still visits tile 0 (all waves idle in it)
+    };
+    auto first_tile = [&](unsigned long act) -> int { return sk ? __builtin_ctzl(act) : 0; };
+    auto next_tile = [&](unsigned long act, int from) -> int {
+        if (!sk) return from < nqt ? from : -1;
+        if (from >= 64) return -1;
+        const unsigned long m = act >> from;
+        return m ? from + __builtin_ctzl(m) : -1;
+    };
+
+    float4 vf[NC];                                                              // V[key][16 c + 4 kk + s] * scale of the current key block
+    auto load_vfrag = [&](int kb) {
+        const int row = kb * 128 + kvl;
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            vf[cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
+            vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale;
+        }
+    };
+
+    int cur_bytes = 0xff, nxt_bytes = 0xff;
+    unsigned long act = load_tiles(0, cur_bytes);
+    unsigned long written = 0;                                                  // bit qt: some key block has stored dQ rows of tile qt
+    dma_group<KPPW>(descK, lds_kb, 0u, vkb);
+    load_vfrag(0);
+    {
+        const int q_first = first_tile(act);
+        issue_q(q_first, 0);
+        issue_do(q_first, 0);
+    }
+    int j = 0;                                                                  // tiles visited: stage and dS-buffer parity
+    int n_inflight = 0;                                                         // vector-memory instructions issued after the last DMA piece
+
+    f32x4 dK[NC], dV[NC], P[2], dS[2];
+    // ---- dQ^T[d, q] (+)= K^T[d, kv] dS^T[kv, q] of tile `tile` over the 128 keys of the block, from dS buffer `buf`;
+    //      `oldq` = what earlier key blocks left there; the DMA pieces of tile `nq` (stage `nstage`) go out inside
+    auto dq_phase = [&](int tile, int buf, const f32x4 (&oldq)[DQT]) __attribute__((always_inline)) {
+        if (dq_wave) {
+            const float *tS = sDS + buf * DSBUF + (NC == 8 ? 0 : dqh * SROWS16);
+            f32x4 acc[DQT];
+#pragma unroll
+            for (int t = 0; t < DQT; ++t) acc[t] = oldq[t];
+            float ak[2][4];
+            float4 da[2][DQT];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) ak[0][s] = sKB[wsK[s]];
+#pragma unroll
+            for (int t = 0; t < DQT; ++t) da[0][t] = ld4(tS + rbS[0] + t * SROWS16);
+#pragma unroll
+            for (int cc = 0; cc < 8; ++cc) {
+                if (cc + 1 < 8) {
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) ak[(cc + 1) & 1][s] = sKB[wsK[s] + (cc + 1) * ROWS16];
+#pragma unroll
+                    for (int t = 0; t < DQT; ++t) da[(cc + 1) & 1][t] = ld4(tS + rbS[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + t * SROWS16);
+                }
+                FENCE();
+#pragma unroll
+                for (int t = 0; t < DQT; ++t) {
+                    acc[t] = MFMA16(ak[cc & 1][0], da[cc & 1][t].x, acc[t]);
+                    acc[t] = MFMA16(ak[cc & 1][1], da[cc & 1][t].y, acc[t]);
+                    acc[t] = MFMA16(ak[cc & 1][2], da[cc & 1][t].z, acc[t]);
+                    acc[t] = MFMA16(ak[cc & 1][3], da[cc & 1][t].w, acc[t]);
+                }
+                FENCE();
+            }
+            const int dq_tile = tile * 32 * (int)p.dq_pitch * 4 + (NC == 8 ? 0 : dqh * dq_sub);
+#pragma unroll
+            for (int t = 0; t < DQT; ++t) {
+                const u32x4_t v = {__float_as_uint(acc[t][0]), __float_as_uint(acc[t][1]), __float_as_uint(acc[t][2]), __float_as_uint(acc[t][3])};
+                __builtin_amdgcn_raw_buffer_store_b128(v, rsrcDQ, dq_voff, dq_tile + t * dq_sub, 0);
+            }
+        }
+    };
+
+    for (int kb = 0; kb < nkb; ++kb) {
+        unsigned long act_n = 0;
+        if (kb + 1 < nkb) act_n = load_tiles(kb + 1, nxt_bytes);
+        const int kvrow = kb * 128 + kvl;
+        const bool kvok = kvrow < p.seq_kv;
+#pragma unroll
+        for (int t = 0; t < NC; ++t) { dK[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        const int svoff = kvok ? (kvrow + 4 * kk * p.seq_kv) * 4 : OOB;          // saved scores: this lane's key, its rows 4 kk ..
+        const int mvoff = kvok ? kvrow + 4 * kk * (int)p.mask_sq : OOB;          // mask bytes, the same way
+
+        int pend = -1;                                                           // tile whose dQ product is still to come
+        f32x4 pend_old[DQT];
+#pragma unroll
+        for (int t = 0; t < DQT; ++t) pend_old[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int qt = first_tile(act);
+        // One visited tile.  Head sizes below 128: the parity of the visit count (Q / dO stage, dS buffer) is a compile-time
+        // constant -- two copies of the body -- so that every LDS address is a lane-dependent register plus an immediate (the
+        // run-time parity costs 21 vector-ALU adds per tile, each of which takes the matrix pipe's issue slot for its cycles).
+        // At head size 128 the register file has no room for the second copy's hoisted bases (it spilled 100 registers):
+        // run-time parity there.
+        auto visit = [&](auto parity) __attribute__((always_inline)) {
+            const int cur = CTP ? (int)decltype(parity)::value : (j & 1);
+            const int nxt = next_tile(act, qt + 1);
+            const bool last = nxt < 0;                                           // last tile of this key block
+            const int nq = !last ? nxt : (kb + 1 < nkb ? first_tile(act_n) : -1);   // the tile whose Q / dO pieces go out in this one
+            // ---- the tile's pieces (and, at a seam, the K block) have landed for every wave; dS of the pending tile is in LDS
+            if (n_inflight == 2 * NC) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            n_inflight = 0;
+            const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
+            float *const tDS = sDS + cur * DSBUF;
+            const int q0 = 32 * qt;
+            const int tile_bits = sk ? __builtin_amdgcn_readlane(cur_bytes, qt & 63) : 0xff;
+            const bool on = !sk || ((tile_bits >> wave) & 1);                        // this wave's 32 x 16 sub-tile has work
+            //                (written with the `!sk ||`: without it hipcc's allocation of this kernel at D = 128 ends 18 registers
+            //                 higher and spills -- the register file is full here, any change to this kernel needs the metadata test)
+            const bool masked_sub = MASK && !((tile_bits >> (8 + wave)) & 1);        // ... and excluded positions (else: no mask bytes)
+
+            // ---- requests of this tile: row terms, raw scores / mask bytes, what earlier key blocks left in its dQ rows
+            f32x4 Lr[2], Dr[2], S[2];
+            unsigned char mk[2][4];
+            if (on) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const u32x4_t l4 = __builtin_amdgcn_raw_buffer_load_b128(rsrcL, 16 * kk, (q0 + 16 * t) * 4, 0);
+                    const u32x4_t d4 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDl, 16 * kk, (q0 + 16 * t) * 4, 0);
+                    Lr[t] = f32x4{__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
+                    Dr[t] = f32x4{__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
+                }
+                if (SAVED) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            S[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, svoff, (q0 + 16 * t + r) * srow_bytes, 2));
+                }
+                if (masked_sub) {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r)
+                            mk[t][r] = __builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff, (q0 + 16 * t + r) * (int)p.mask_sq, 0);
+                }
+            }
+
+            // ---- the pending tile's dQ product
+            if (pend >= 0) dq_phase(pend, cur ^ 1, pend_old);          // the tile visited before this one: the other dS buffer
+            // (what earlier key blocks left in THIS tile's dQ rows is requested only now: the pending tile's values are consumed,
+            // one set of registers serves both; the values are needed a tile from now, or behind this tile's dV product)
+            f32x4 own_old[DQT];
+#pragma unroll
+            for (int t = 0; t < DQT; ++t) own_old[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (dq_wave) {
+                const auto rsrcOld = ((written >> (qt & 63)) & 1) || (!sk && kb > 0) ? rsrcDQ : rsrcNone;     // nothing stored yet: reads 0
+                const int dq_tile = q0 * (int)p.dq_pitch * 4 + (NC == 8 ? 0 : dqh * dq_sub);
+#pragma unroll
+                for (int t = 0; t < DQT; ++t) {
+                    const u32x4_t o = __builtin_amdgcn_raw_buffer_load_b128(rsrcOld, dq_voff, dq_tile + t * dq_sub, 0);
+                    own_old[t] = f32x4{__uint_as_float(o.x), __uint_as_float(o.y), __uint_as_float(o.z), __uint_as_float(o.w)};
+                }
+            }
+            if (sk) written |= 1ul << (qt & 63);
+
+            if (on) {
+                float4 fa[2][2];
+                if (!SAVED) {
+                    // ---- S[q, kv] = Q K^T: NC steps of (3 row reads, 8 MFMAs), reads one step ahead
+                    S[0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    float4 fk[2];
+                    fa[0][0] = ld4(tQ + rb[0]);
+                    fa[0][1] = ld4(tQ + rb[0] + ROWS16);
+                    fk[0] = ld4(sKW + rb[0]);
+#pragma unroll
+                    for (int cc = 0; cc < NC; ++cc) {
+                        if (cc + 1 < NC) {
+                            fa[(cc + 1) & 1][0] = ld4(tQ + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
+                            fa[(cc + 1) & 1][1] = ld4(tQ + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + ROWS16);
+                            fk[(cc + 1) & 1] = ld4(sKW + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
+                        }
+                        FENCE();
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            S[t] = MFMA16(fa[cc & 1][t].x, fk[cc & 1].x, S[t]);
+                            S[t] = MFMA16(fa[cc & 1][t].y, fk[cc & 1].y, S[t]);
+                            S[t] = MFMA16(fa[cc & 1][t].z, fk[cc & 1].z, S[t]);
+                            S[t] = MFMA16(fa[cc & 1][t].w, fk[cc & 1].w, S[t]);
+                        }
+                        FENCE();
+                    }
+                }
+                // ---- dP[q, kv] - delta[q] = dO V^T - delta: NC steps of (2 row reads, 8 MFMAs), reads one step ahead.  The
+                //      accumulators START from -delta (the row term has the accumulator's layout: rows 4 kk + r): no zeroing,
+                //      no subtraction afterwards
+                f32x4 dP[2] = {Dr[0], Dr[1]};
+                fa[0][0] = ld4(tDO + rb[0]);
+                fa[0][1] = ld4(tDO + rb[0] + ROWS16);
+#pragma unroll
+                for (int cc = 0; cc < NC; ++cc) {
+                    if (cc + 1 < NC) {
+                        fa[(cc + 1) & 1][0] = ld4(tDO + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
+                        fa[(cc + 1) & 1][1] = ld4(tDO + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + ROWS16);
+                    }
+                    FENCE();
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        dP[t] = MFMA16(fa[cc & 1][t].x, vf[cc].x, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].y, vf[cc].y, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].z, vf[cc].z, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].w, vf[cc].w, dP[t]);
+                    }
+                    FENCE();
+                }
+                // ---- P = exp2(c S - log2(e) LSE); dS = P (dP - delta) (both carry the 1 / sqrt(Dk) already), also into LDS
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        float pr = fast_exp2(fmaf(S[t][r], c, -Lr[t][r]));
+                        if (masked_sub && mk[t][r] == 0) pr = 0.f;
+                        P[t][r] = pr;
+                        dS[t][r] = pr * dP[t][r];
+                        tDS[wsS[r] + t * SROWS16] = dS[t][r];
+                    }
+                // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (NV vector reads, NC MFMAs)
+                float ea[2][NV][4];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) ldv<VW>(tDO + vb[0] + 64 * v, ea[0][v]);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    const int t = st >> 2, r = st & 3;
+                    if (st + 1 < 8) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) ldv<VW>(tDO + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16 + 64 * v, ea[(st + 1) & 1][v]);
+                    }
+                    // The next tile's Q / dO pieces go out HERE: behind every load whose result this tile still waits for (the
+                    // compiler's counted waits do not see them: a wait placed after them would drain them too), a phase and a
+                    // half ahead of their use.
+                    if (st == 1 && nq >= 0) issue_q(nq, cur ^ 1);
+                    if (st == 5 && nq >= 0) issue_do(nq, cur ^ 1);
+                    FENCE();
+#pragma unroll
+                    for (int x = 0; x < NC; ++x) dV[x] = MFMA16(ea[st & 1][x / VW][x % VW], P[t][r], dV[x]);
+                    FENCE();
+                }
+            } else {
+#pragma unroll
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) tDS[wsS[r] + t * SROWS16] = 0.f;
+                if (nq >= 0) {
+                    issue_q(nq, cur ^ 1);
+                    issue_do(nq, cur ^ 1);
+                }
+            }
+
+            if (last) {
+                // ---- this tile's own dQ product now (the K block is replaced next): dS of all eight key groups must be in LDS
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                dq_phase(qt, cur, own_old);
+                if (kb + 1 < nkb) {                    // every wave is done with this K block: request the next one
+                    __builtin_amdgcn_s_barrier();
+                    asm volatile("" ::: "memory");
+                    dma_group<KPPW>(descK, lds_kb, (unsigned)((kb + 1) * 128 * p.k_pitch * 4), vkb);
+                    load_vfrag(kb + 1);
+                }
+                pend = -1;
+            } else {
+                pend = qt;
+#pragma unroll
+                for (int t = 0; t < DQT; ++t) pend_old[t] = own_old[t];
+            }
+
+            if (on) {
+                // ---- dK^T[d, kv] += Q^T[d, q] dS[q, kv]
+                float ea[2][NV][4];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) ldv<VW>(tQ + vb[0] + 64 * v, ea[0][v]);
+#pragma unroll
+                for (int st = 0; st < 8; ++st) {
+                    const int t = st >> 2, r = st & 3;
+                    if (st + 1 < 8) {
+#pragma unroll
+                        for (int v = 0; v < NV; ++v) ldv<VW>(tQ + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16 + 64 * v, ea[(st + 1) & 1][v]);
+                    }
+                    FENCE();
+#pragma unroll
+                    for (int x = 0; x < NC; ++x) dK[x] = MFMA16(ea[st & 1][x / VW][x % VW], dS[t][r], dK[x]);
+                    FENCE();
+                }
+            }
+            ++j;
+            qt = nxt;
+            FENCE();
+        };
+        while (qt >= 0) {
+            if (CTP && (j & 1)) visit(std::integral_constant<int, 1>{});
+            else visit(std::integral_constant<int, 0>{});
+        }
+        // ---- this block's dK and dV rows: lane = key; for a fixed register r the d-tiles of one vector read are VW adjacent
+        //      head dimensions, and r = 0 .. 3 continue them: 16 bytes per store
+#pragma unroll
+        for (int x4 = 0; x4 < (NC + 3) / 4; ++x4)
+#pragma unroll
+            for (int r0 = 0; r0 < 4; r0 += 4 / VW) {
+                // d0 = first head dimension of this store: tiles x = 4 x4 .. (VW per register), registers r0 .. r0 + 4 / VW - 1
+                const int d0 = 64 * x4 + VW * (4 * kk + r0);
+                const int offk = kvok ? (int)((kvrow * p.dk_pitch + d0) * 4) : OOB, offv = kvok ? (int)((kvrow * p.dv_pitch + d0) * 4) : OOB;
+                float k4[4], v4[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int x = 4 * x4 + e % VW, r = r0 + e / VW;
+                    k4[e] = dK[x < NC ? x : 0][r & 3];
+                    v4[e] = dV[x < NC ? x : 0][r & 3];
+                }
+                buf_store4(rsrcDK, offk, k4[0], k4[1], k4[2], k4[3]);
+                buf_store4(rsrcDV, offv, v4[0], v4[1], v4[2], v4[3]);
+            }
+        n_inflight = 2 * NC;
+        act = act_n;
+        cur_bytes = nxt_bytes;
+    }
+    // ---- query tiles no key block visited (every position masked): their dQ rows are zero
+    if (sk && dq_wave) {
+        for (int qt = 0; qt < nqt; ++qt) {
+            if ((written >> (qt & 63)) & 1) continue;
+            const int dq_tile = qt * 32 * (int)p.dq_pitch * 4 + (NC == 8 ? 0 : dqh * dq_sub);
+            const u32x4_t zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int t = 0; t < DQT; ++t) __builtin_amdgcn_raw_buffer_store_b128(zero, rsrcDQ, dq_voff, dq_tile + t * dq_sub, 0);
+        }
+    }
+}
+
 long long *g_attn_trace = nullptr;
 int g_attn_stagger = 1;
-int g_attn_bwd16 = 1;          // NPM_TUNE_ATTN_BWD16: head size 128 with saved scores on the 8-wave 16 x 16 x 4 kernel
+int g_attn_pair = 1;           // forward with a tile summary: two query tiles per block (see mha_fwd_kernel); NPM_TUNE_ATTN_STAGGER's bit 8 clears it
+int g_attn_bwd16 = 2;          // NPM_TUNE_ATTN_BWD16: 2 (default) mha_bwd8_kernel, except head size 128 with saved scores and no tile
+                               // summary, which stays on mha_bwd16_kernel (4.59 against 4.86 ms at C4: fewer vector-ALU instructions per
+                               // tile); 3 mha_bwd8_kernel for everything; 1 round 3's choice (mha_bwd16_kernel for head size 128 with
+                               // saved scores, the 4-wave kernel otherwise); 0 the 4-wave kernel always
 char g_attn_last[96] = "";     // npm_last_attn_kernel: what the most recent npm_mha_core_* call launched
 
 void note_kernel(const char *name, int d, bool mask, bool saved) {
@@ -1053,6 +1578,76 @@ mha_delta_kernel(const float *__restrict__ dctx, long dctx_pitch, const float *_
     }
 }
 
+// Row terms for mha_bwd8_kernel: MINUS delta (delta as above) and lse2 = log2(e) * LSE, both [B, H, sq_pad] with zeros in the padding
+// (sq_pad = seq rounded up to whole 32-query tiles), so that the kernel's 16-byte row-term loads never straddle the end.
+__global__ void __launch_bounds__(256)
+mha_rowterms_kernel(const float *__restrict__ dctx, long dctx_pitch, const float *__restrict__ ctx, long ctx_pitch,
+                    const float *__restrict__ lse, float *__restrict__ delta, float *__restrict__ lse2,
+                    long batch, long seq, long sq_pad, int heads, int dim, float scale) {
+    const long rows = batch * sq_pad * heads;
+    const int sub = threadIdx.x & 31;
+    const long row = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 5;
+    if (row >= rows) return;
+    const long bs = row / heads;
+    const int h = (int)(row - bs * heads);
+    const long s_ = bs % sq_pad, b_ = bs / sq_pad;
+    const long out = (b_ * heads + h) * sq_pad + s_;
+    if (s_ >= seq) {
+        if (sub == 0) { delta[out] = 0.f; lse2[out] = 0.f; }
+        return;
+    }
+    const long src = b_ * seq + s_;
+    const float *pa = dctx + src * dctx_pitch + (long)h * dim, *pb = ctx + src * ctx_pitch + (long)h * dim;
+    float acc = 0.f;
+    for (int c0 = sub * 4; c0 < dim; c0 += 128) {
+        const float4 x = ld4(pa + c0), y = ld4(pb + c0);
+        acc += (x.x * y.x + x.y * y.y) + (x.z * y.z + x.w * y.w);
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 64);
+    if (sub == 0) {
+        delta[out] = -acc * scale;                    // NEGATED: the kernel starts its dP accumulators from it (dP - delta for free)
+        lse2[out] = lse[(b_ * heads + h) * seq + s_] * LOG2E;
+    }
+}
+
+// Tile summary of a mask: byte (qt, kb) of plane (b, h) has bit w set when some position of queries 32 qt .. 32 qt + 31 x keys
+// 128 kb + 16 w .. + 15 is allowed; a second array of the same shape behind it (`total` bytes later) has the bit set when EVERY
+// position of the sub-tile that lies inside the tensors is.  One block per (plane, qt, kb): thread = (query row, 16-key group).
+__global__ void __launch_bounds__(256)
+mha_mask_summary_kernel(const unsigned char *__restrict__ mask, long sb, long sh, long sq, int nh, int seq_q, int seq_kv,
+                        int nqt, int nkb, long total, unsigned char *__restrict__ out) {
+    __shared__ unsigned bits;
+    const long blk = blockIdx.x;
+    const int kb = (int)(blk % nkb), qt = (int)((blk / nkb) % nqt);
+    const long plane = blk / ((long)nkb * nqt);
+    const int hh = (int)(plane % nh);
+    const long bb = plane / nh;
+    if (threadIdx.x == 0) bits = 0;
+    __syncthreads();
+    const int row = qt * 32 + (threadIdx.x >> 3), w = threadIdx.x & 7;
+    unsigned any = 0, hole = 0, inside = 0;
+    if (row < seq_q) {
+        const unsigned char *src = mask + bb * sb + hh * sh + (long)row * sq;
+        const int k0 = kb * 128 + w * 16;
+        for (int i = 0; i < 16; ++i)
+            if (k0 + i < seq_kv) {
+                any |= src[k0 + i];
+                hole |= src[k0 + i] == 0;
+                inside = 1;
+            }
+    }
+    // bits 0..7: some position allowed; 8..15: some position excluded; 16..23: the sub-tile has positions inside the tensors
+    if (any) atomicOr(&bits, 1u << w);
+    if (hole) atomicOr(&bits, 0x100u << w);
+    if (inside) atomicOr(&bits, 0x10000u << w);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        out[blk] = (unsigned char)bits;
+        out[total + blk] = (unsigned char)((bits >> 16) & ~(bits >> 8));      // "all": in range and no excluded position
+    }
+}
+
 // The s_memtime stamps of npm_debug_attn_trace live in instances of their own (D = 128, no mask): the product
 // instances carry no trace code at all (each stamp is an exec-masked branch in a loop where every instruction counts).
 template <int D, bool MASK, bool SAVE>
@@ -1063,7 +1658,7 @@ void launch_fwd_instance(const MhaArgs &a, int grid, hipStream_t s) {
 
 template <int D>
 int launch_fwd(const MhaArgs &a, hipStream_t s) {
-    const int grid = a.batch * a.heads * a.q_tiles;
+    const int grid = a.batch * a.heads * (a.q_pair ? (a.q_tiles + 1) / 2 : a.q_tiles);
     const bool mask = a.mask != nullptr, save = a.scores != nullptr;
     if (mask && save) launch_fwd_instance<D, true, true>(a, grid, s);
     else if (mask) launch_fwd_instance<D, true, false>(a, grid, s);
@@ -1081,13 +1676,25 @@ void launch_bwd_instance(const MhaArgs &a, int grid, hipStream_t s) {
 }
 
 template <int D>
+int launch_bwd8(const MhaArgs &a, hipStream_t s) {
+    const int grid = a.batch * a.heads;
+    const bool mask = a.mask != nullptr, saved = a.scores != nullptr;
+    if (saved) hipLaunchKernelGGL((mha_bwd8_kernel<D, false, true>), dim3(grid), dim3(512), 0, s, a);
+    else if (mask) hipLaunchKernelGGL((mha_bwd8_kernel<D, true, false>), dim3(grid), dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((mha_bwd8_kernel<D, false, false>), dim3(grid), dim3(512), 0, s, a);
+    note_kernel("mha_bwd8_kernel", D, mask && !saved, saved);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+template <int D>
 int launch_bwd(const MhaArgs &a, hipStream_t s) {
     const int grid = a.batch * a.heads;
     const bool mask = a.mask != nullptr, saved = a.scores != nullptr;
     // Saved scores already CARRY the mask (the forward stored -inf at every masked position, so P = exp2(-inf) = 0
     // there): the backward needs the mask bytes only when it recomputes q.k.  One instance less per head size -- the
     // one whose 16 extra byte loads per tile did not fit the register file at D = 128.
-    const bool wide = saved && D == 128 && g_attn_bwd16 && !a.trace;
+    const bool wide = saved && D == 128 && (g_attn_bwd16 == 1 || g_attn_bwd16 == 2) && !a.trace;
     if (wide) hipLaunchKernelGGL(mha_bwd16_kernel, dim3(grid), dim3(512), 0, s, a);
     else if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
     else if (mask) launch_bwd_instance<D, true, false>(a, grid, s);
@@ -1119,12 +1726,23 @@ int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
     a.ctx = c->ctx; a.ctx_pitch = c->ctx_pitch; a.lse = c->lse;
     a.mask = c->mask; a.mask_sb = c->mask_stride_b; a.mask_sh = c->mask_stride_h; a.mask_sq = c->mask_stride_q;
     a.scores = c->scores;
+    // tile summary: the kernels keep one bit per tile in a 64-bit scalar, so sequences beyond 2048 just do not skip
+    // (and the older backward kernels know nothing of it: with them selected the forward must write every score)
+    if (c->mask && c->tile_summary && c->seq_q <= 2048 && c->seq_kv <= 2048 && g_attn_bwd16 >= 2) {
+        NPM_ARG(c->summary_stride_b >= 0 && c->summary_stride_h >= 0);
+        a.skip = c->tile_summary;
+        a.skip_sb = c->summary_stride_b;
+        a.skip_sh = c->summary_stride_h;
+        a.skip_nkb = (c->seq_kv + 127) / 128;
+        a.skip_all = c->summary_all_offset > 0 ? c->summary_all_offset : 0;
+    }
     NPM_ARG(!c->scores || al16(c->scores));
     NPM_ARG(!c->scores || ((int64_t)c->seq_q + 32) * c->seq_kv * 4 < (1LL << 31));      // one (b, h) score matrix behind one descriptor
     NPM_ARG(!c->mask || (c->mask_stride_q >= 0 && ((int64_t)c->seq_q + 32) * c->mask_stride_q + c->seq_kv < (1LL << 31)));
     a.batch = c->batch; a.heads = c->heads; a.seq_q = c->seq_q; a.seq_kv = c->seq_kv;
     a.scale = c->scale;
     a.q_tiles = (c->seq_q + 127) / 128;
+    a.q_pair = a.skip != nullptr && a.q_tiles >= 2 && g_attn_pair;
     a.trace = g_attn_trace;
     a.stagger = g_attn_stagger;
     if (backward) {
@@ -1142,10 +1760,29 @@ int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
 }  // namespace
 
 extern "C" int npm_debug_attn_trace(long long *buf) { g_attn_trace = buf; return NPM_OK; }
-extern "C" int npm_attn_set_stagger(int units) { g_attn_stagger = units < 0 ? 0 : units; return NPM_OK; }
-extern "C" int npm_attn_set_bwd16(int on) { g_attn_bwd16 = on != 0; return NPM_OK; }
+extern "C" int npm_attn_set_stagger(int units) {
+    g_attn_pair = !(units >= 0 && (units & 256));
+    g_attn_stagger = units < 0 ? 0 : (units & 255);
+    return NPM_OK;
+}
+extern "C" int npm_attn_set_bwd16(int on) { g_attn_bwd16 = on < 0 ? 0 : on > 3 ? 3 : on; return NPM_OK; }
 
 extern "C" const char *npm_last_attn_kernel(void) { return g_attn_last; }
+
+extern "C" int npm_mha_mask_summary(const uint8_t *mask, int64_t stride_b, int64_t stride_h, int64_t stride_q, int32_t planes_b,
+                                    int32_t planes_h, int32_t seq_q, int32_t seq_kv, uint8_t *summary) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(mask && summary && planes_b >= 1 && planes_h >= 1 && seq_q >= 0 && seq_kv >= 1);
+    NPM_ARG(stride_b >= 0 && stride_h >= 0 && stride_q >= 0);
+    const int nqt = (seq_q + 31) / 32, nkb = (seq_kv + 127) / 128;
+    const long blocks = (long)planes_b * planes_h * nqt * nkb;
+    if (blocks == 0) return NPM_OK;
+    NPM_ARG(blocks < (1L << 31));
+    hipLaunchKernelGGL(mha_mask_summary_kernel, dim3((int)blocks), dim3(256), 0, npm::ctx().stream, mask, (long)stride_b, (long)stride_h,
+                       (long)stride_q, planes_h, seq_q, seq_kv, nqt, nkb, blocks, summary);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
 
 extern "C" int npm_mha_core_supported(int head_dim) { return head_dim == 16 || head_dim == 32 || head_dim == 64 || head_dim == 128; }
 
@@ -1180,6 +1817,28 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
         return NPM_OK;
     }
     npm::Scratch ws;                                  // stream-ordered pool: safe to release when this call returns
+    const bool wide128 = c->head_dim == 128 && a.scores != nullptr && a.skip == nullptr;      // the case mha_bwd16_kernel was built for
+    if ((g_attn_bwd16 == 3 || (g_attn_bwd16 == 2 && !wide128)) && !a.trace) {
+        // mha_bwd8_kernel: row terms padded to whole query tiles ([B, H, sq_pad] each: delta, then log2(e) LSE)
+        a.sq_pad = (a.seq_q + 31) / 32 * 32;
+        const long padded = (long)a.batch * a.heads * a.sq_pad;
+        rc = ws.alloc(sizeof(float) * 2 * (size_t)padded);
+        if (rc) return rc;
+        a.delta = (float *)ws.ptr;
+        a.lse2 = a.delta + padded;
+        NPM_ARG((padded * 32 + 255) / 256 < (1L << 31));
+        hipLaunchKernelGGL(mha_rowterms_kernel, dim3((int)((padded * 32 + 255) / 256)), dim3(256), 0, s, a.dctx, a.dctx_pitch,
+                           (const float *)a.ctx, a.ctx_pitch, (const float *)a.lse, a.delta, a.lse2, (long)a.batch, (long)a.seq_q,
+                           (long)a.sq_pad, a.heads, c->head_dim, a.scale);
+        NPM_CHECK_LAUNCH();
+        npm::note_math(NPM_MATH_F32);
+        switch (c->head_dim) {
+            case 16: return launch_bwd8<16>(a, s);
+            case 32: return launch_bwd8<32>(a, s);
+            case 64: return launch_bwd8<64>(a, s);
+            default: return launch_bwd8<128>(a, s);
+        }
+    }
     const long rows = (long)a.batch * a.seq_q * a.heads;
     rc = ws.alloc(sizeof(float) * (size_t)rows);
     if (rc) return rc;

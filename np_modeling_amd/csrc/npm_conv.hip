@@ -26,6 +26,8 @@ struct ConvArgs {
     int H, W, C, ks, pad;
     int M, N, K;         // GEMM view
     int tiles_m, tiles_n, splits, k_per_split, group_m;
+    int korder;          // forward / grad_x K loop: 0 = taps outermost (kk = tap * C + c), 1 = 16-channel chunks outermost, the
+                         // k * k taps of a chunk back to back (NPM_TUNE_CONV_KORDER)
     long slab;
     Epilogue e;
 };
@@ -297,11 +299,15 @@ conv_fwd_glds_kernel(const ConvArgs p) {
                 lds_dma16(rsrcA, sa + 256 * i, ok ? vbase[i] : (unsigned)OOB_OFFSET, soff);                  \
             }                                                                                                \
         }                                                                                                    \
-        const unsigned kb = (unsigned)((KT) * GK * p.N * 4);                                                 \
+        const unsigned kb = (unsigned)((((ti * p.ks + tj) * p.C) + c0) * p.N * 4);   /* filter row (tap, c0) */  \
         _Pragma("unroll") for (int i = 0; i < B_PIECES; ++i)                                                 \
             lds_dma16(rsrcB, sb + 256 * i, vb[i], kb);                                                       \
-        c0 += GK;                                                                                            \
-        if (c0 == p.C) { c0 = 0; if (++tj == p.ks) { tj = 0; ++ti; } }                                       \
+        if (p.korder) {                                                                                      \
+            if (++tj == p.ks) { tj = 0; if (++ti == p.ks) { ti = 0; c0 += GK; } }                            \
+        } else {                                                                                             \
+            c0 += GK;                                                                                        \
+            if (c0 == p.C) { c0 = 0; if (++tj == p.ks) { tj = 0; ++ti; } }                                   \
+        }                                                                                                    \
     } while (0)
 
     f32x16 acc[2][2];
@@ -668,6 +674,7 @@ inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
 int g_conv_wave_prio = 0;   // NPM_TUNE_GEMM_WAVE_PRIO
 int g_conv_math = 0;        // NPM_TUNE_GEMM_MATH
+int g_conv_korder = 1;      // NPM_TUNE_CONV_KORDER: 1 (default) 16-channel chunks outermost, 0 taps outermost
 int g_wgrad_fused = 1;           // NPM_TUNE_CONV_WGRAD_FUSED: 0 two passes (ReLU backward, then grad_w), 1 fused (tile height picked), 2 / 3 fused with 128- / 192-row tiles
 int g_wgrad_blocks_per_cu = 0;   // NPM_TUNE_CONV_WGRAD_BLOCKS: 0 pick_splits chooses 3 or 4 blocks per CU, 3 / 4 pins it, -1 the old ceil(3 CUs / tiles)
 
@@ -682,6 +689,7 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.N + BN - 1) / BN;
     a.splits = 1; a.k_per_split = a.K; a.group_m = 8;
+    a.korder = g_conv_korder;
     a.e = e;
     const bool vec = c % 4 == 0 && n_out % 4 == 0 && aligned16(x) && aligned16(filt_kn);
     hipStream_t s = npm::ctx().stream;
@@ -716,6 +724,7 @@ extern "C" int npm_conv_set_dma(int on) { g_conv_dma = on; return NPM_OK; }
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu) { g_wgrad_blocks_per_cu = per_cu; return NPM_OK; }
 extern "C" int npm_conv_set_wave_prio(int bits) { g_conv_wave_prio = bits; return NPM_OK; }
 extern "C" int npm_conv_set_math(int mode) { g_conv_math = mode; return NPM_OK; }
+extern "C" int npm_conv_set_korder(int order) { g_conv_korder = order != 0; return NPM_OK; }
 extern "C" int npm_conv_set_wgrad_fused(int mode) { g_wgrad_fused = mode; return NPM_OK; }
 
 extern "C" {

@@ -429,6 +429,7 @@ int launch_splitk_reduce(const ReduceArgs &r, hipStream_t stream) {
 extern "C" int npm_conv_set_dma(int on);
 extern "C" int npm_conv_set_wgrad_blocks(int per_cu);
 extern "C" int npm_conv_set_wave_prio(int bits);
+extern "C" int npm_conv_set_korder(int order);
 extern "C" int npm_conv_set_math(int mode);
 extern "C" int npm_conv_set_wgrad_fused(int mode);
 extern "C" int npm_attn_set_bwd16(int on);
@@ -458,6 +459,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_ATTN_STAGGER: return npm_attn_set_stagger(value);
         case NPM_TUNE_ATTN_BWD16: return npm_attn_set_bwd16(value);
         case NPM_TUNE_KSYNC: npm::set_ksync_every(value); return NPM_OK;
+        case NPM_TUNE_CONV_KORDER: return npm_conv_set_korder(value);
         case NPM_TUNE_STREAM_NT: npm::set_stream_nt(value); return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }

@@ -345,6 +345,12 @@ class ByteBuffer:
         self._buf = _Buffer(nbytes)
         self.ptr, self.nbytes = self._buf.ptr, int(nbytes)
 
+    def numpy(self) -> np.ndarray:
+        host = np.empty([self.nbytes], dtype=np.uint8)
+        if self.nbytes:
+            _C.check(_C.lib().npm_d2h(host.ctypes.data, self.ptr, self.nbytes), 'npm_d2h')
+        return host
+
     def __deepcopy__(self, memo):
         out = ByteBuffer.__new__(ByteBuffer)
         out._buf = self._buf.__deepcopy__(memo)
@@ -425,6 +431,8 @@ ATTN_CORE = os.environ.get('NPM_ATTN_CORE', '1') != '0'            # fused atten
 # resource (a 32 x 32 score tile costs 64 MFMAs to recompute, 16 loads to read back; measured 5.25 vs 5.86 ms for the
 # C4 backward); NPM_ATTN_SAVE_SCORES=0 is the memory-lean mode (log-sum-exp only, 2.1 GB less at C4 / C5).
 ATTN_SAVE_SCORES = os.environ.get('NPM_ATTN_SAVE_SCORES', '1') != '0'
+# masked attention: let the fused kernels skip tiles without an allowed position (NPM_ATTN_TILE_SKIP=0: visit them all)
+ATTN_TILE_SKIP = os.environ.get('NPM_ATTN_TILE_SKIP', '1') != '0'
 
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its
@@ -678,6 +686,16 @@ class AttnMask:
         self.buf = bytes_from_host(host)
         nb, nh, nq, _ = host.shape
         self.strides = (0 if nb == 1 else nh * nq * skv, 0 if nh == 1 else nq * skv, 0 if nq == 1 else skv)
+        # Tile summary (include/npm_hip.h npm_mha_mask_summary): one byte per (32 queries, 128 keys) and distinct mask plane,
+        # made on the device from the bytes just uploaded; the fused kernels skip the tiles it marks empty.
+        self.summary, self.summary_strides = None, (0, 0)
+        if ATTN_TILE_SKIP and sq > 0:
+            nqt, nkb = (sq + 31) // 32, (skv + 127) // 128
+            self.summary_all_offset = nb * nh * nqt * nkb          # "every position allowed" bytes: the second half
+            self.summary = ByteBuffer(2 * self.summary_all_offset)
+            _C.check(_C.lib().npm_mha_mask_summary(self.buf.ptr, self.strides[0], self.strides[1], self.strides[2], nb, nh, sq, skv,
+                                                   self.summary.ptr), 'npm_mha_mask_summary')
+            self.summary_strides = (0 if nb == 1 else nh * nqt * nkb, 0 if nh == 1 else nqt * nkb)
 
     def full(self, b, h, sq, skv) -> np.ndarray:
         return np.broadcast_to(self.host, (b, h, sq, skv))
@@ -694,6 +712,10 @@ def _core_desc(q: Mat, k: Mat, v: Mat, ctx: Mat, lse: DeviceArray, dims, scale: 
     if mask is not None:
         c.mask = mask.buf.ptr
         c.mask_stride_b, c.mask_stride_h, c.mask_stride_q = mask.strides
+        if mask.summary is not None:
+            c.tile_summary = mask.summary.ptr
+            c.summary_stride_b, c.summary_stride_h = mask.summary_strides
+            c.summary_all_offset = mask.summary_all_offset
     if scores is not None:
         c.scores = scores.ptr
     return c

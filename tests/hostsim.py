@@ -231,6 +231,25 @@ class HostSim:
         return 0
 
     # ---- fused attention core ------------------------------------------------------------------------
+    def npm_mha_mask_summary(self, mask, sb, sh, sq_stride, nb, nh, seq_q, seq_kv, out):
+        """byte (qt, kb) of plane (b, h): bit w = some allowed position in queries 32 qt.. x keys 128 kb + 16 w.. (include/npm_hip.h)"""
+        self.calls.append('npm_mha_mask_summary')
+        nqt, nkb = (seq_q + 31) // 32, (seq_kv + 127) // 128
+        extent = (nb - 1) * sb + (nh - 1) * sh + (seq_q - 1) * sq_stride + seq_kv
+        raw = np.ctypeslib.as_array((C.c_ubyte * int(extent)).from_address(_addr(mask)))
+        planes = np.lib.stride_tricks.as_strided(raw, shape=(nb, nh, seq_q, seq_kv), strides=(sb, sh, sq_stride, 1))
+        padded = np.zeros((nb, nh, nqt * 32, nkb * 128), dtype=bool)
+        padded[:, :, :seq_q, :seq_kv] = planes != 0
+        inside = np.zeros_like(padded)
+        inside[:, :, :seq_q, :seq_kv] = True
+        split = lambda a: a.reshape(nb, nh, nqt, 32, nkb, 8, 16)
+        any16 = split(padded).any(axis=(3, 6))                                          # [nb, nh, nqt, nkb, 8]
+        all16 = split(padded | ~inside).all(axis=(3, 6)) & split(inside).any(axis=(3, 6))
+        pack = lambda bits: (bits << np.arange(8)).sum(axis=-1).astype(np.uint8).reshape(-1)
+        both = np.concatenate([pack(any16), pack(all16)])
+        np.ctypeslib.as_array((C.c_ubyte * both.size).from_address(_addr(out)))[:] = both
+        return 0
+
     def npm_mha_core_supported(self, head_dim):
         return int(head_dim in (16, 32, 64, 128))
 

@@ -29,7 +29,19 @@ def npm():
     return np_modeling_amd
 
 
-def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=False, lse_ctx=None):
+@pytest.fixture(params=[3, 2, 1, 0], ids=['bwd8', 'default', 'bwd16', 'bwd4'], autouse=True)
+def bwd_kernel(request, npm):
+    """Every test of this module under each choice of the attention backward (NPM_TUNE_ATTN_BWD16, include/npm_hip.h):
+    3 = mha_bwd8_kernel always (8 waves, one barrier per tile, every head size), 2 = the default (the same, except head size 128
+    with saved scores and no tile summary -> mha_bwd16_kernel), 1 = round 3's choice (mha_bwd16_kernel for head size 128 with saved
+    scores, else the 4-wave kernel), 0 = the 4-wave kernel."""
+    from np_modeling_amd import _C
+    _C.check(_C.lib().npm_set_tuning(14, request.param), 'npm_set_tuning')
+    yield request.param
+    _C.check(_C.lib().npm_set_tuning(14, 2), 'npm_set_tuning')
+
+
+def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=False, lse_ctx=None, skip=True):
     """q [B,Sq,H,D], k/v [B,Skv,H,D] host arrays -> dict of host results from the C ABI.  ``packed``: q, k, v
     live in one [B, S, 3, H, D] buffer (row pitch 3 H D), like the layer's packed projection."""
     from np_modeling_amd import _C, device as D
@@ -59,6 +71,10 @@ def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=Fals
         mask_dev = D.AttnMask(mask, b, h, sq, skv)
         c.mask = mask_dev.buf.ptr
         c.mask_stride_b, c.mask_stride_h, c.mask_stride_q = mask_dev.strides
+        if skip and mask_dev.summary is not None:               # the mask's tile summary: the kernels skip empty tiles
+            c.tile_summary = mask_dev.summary.ptr
+            c.summary_stride_b, c.summary_stride_h = mask_dev.summary_strides
+            c.summary_all_offset = mask_dev.summary_all_offset
     scores = None
     if save:
         scores = D.full([b * h * sq * skv + guard], 777.0)
@@ -136,13 +152,13 @@ def test_core_vs_oracle(npm, b, h, sq, skv, d):
 
 @pytest.mark.parametrize('b,h,sq,skv', [(1, 1, 1, 1), (2, 3, 32, 32), (2, 2, 33, 47), (1, 2, 100, 257), (1, 3, 200, 130),
                                          (3, 1, 31, 300), (1, 1, 130, 5), (1, 2, 512, 512), (2, 1, 17, 128), (1, 1, 64, 129)])
-@pytest.mark.parametrize('bwd16', [1, 0])
-def test_core_saved_scores_head_128(npm, b, h, sq, skv, bwd16):
-    """Head size 128 with saved scores -- the default path of C4 / C5 -- through ragged lengths: the backward is the
-    8-wave kernel on v_mfma_f32_16x16x4_f32 (mha_bwd16_kernel: 16 keys per wave, two waves per SIMD; NPM_TUNE_ATTN_BWD16
-    = 1, default) or the 4-wave 32x32x2 kernel (= 0); both against the oracle, and the saved scores themselves."""
+def test_core_saved_scores_head_128(npm, b, h, sq, skv, bwd_kernel):
+    """Head size 128 with saved scores -- the default path of C4 / C5 -- through ragged lengths, under each backward kernel
+    (the module's ``bwd_kernel`` fixture): mha_bwd8_kernel, mha_bwd16_kernel, the 4-wave 32x32x2 kernel; against the oracle,
+    and the saved scores themselves."""
     from np_modeling_amd import _C
     d = 128
+    bwd16 = bwd_kernel
     rng = np.random.default_rng(b * 1000 + sq * 7 + skv)
     q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
     k = rng.standard_normal([b, skv, h, d]).astype(np.float32)
@@ -152,11 +168,8 @@ def test_core_saved_scores_head_128(npm, b, h, sq, skv, bwd16):
     q64, k64, v64, d64 = (x.astype(np.float64) for x in (q, k, v, dctx))
     ctx, lse, probs = O.attention_core_fwd(q64, k64, v64, scale)
     dq, dk, dv = O.attention_core_bwd(q64, k64, v64, probs, d64, scale)
-    _C.check(_C.lib().npm_set_tuning(14, bwd16), 'npm_set_tuning')
-    try:
-        got = _run_core(npm, q, k, v, scale, dctx=dctx, save=True)
-    finally:
-        _C.check(_C.lib().npm_set_tuning(14, 1), 'npm_set_tuning')
+    got = _run_core(npm, q, k, v, scale, dctx=dctx, save=True)
+    assert _C.last_attn_kernel().startswith({3: 'mha_bwd8_kernel', 2: 'mha_bwd16_kernel', 1: 'mha_bwd16_kernel', 0: 'mha_bwd_kernel'}[bwd16] + ' D=128')
     assert_close(got['ctx'], ctx, tol=2e-6)
     assert_close(got['scores'], np.einsum('bqhd,bkhd->bhqk', q64, k64), tol=2e-6)
     for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
@@ -236,6 +249,119 @@ def test_core_masks_that_hide_whole_leading_tiles(npm, d):
             np.testing.assert_allclose(got['lse'], lse, rtol=0, atol=3e-6)
             for g, want in (('dq', dq), ('dk', dk), ('dv', dv)):
                 assert_close(got[g], want, tol=3e-6, what=f'{name} {g} save={save}')
+
+
+def _summary_numpy(full, every=False):
+    """byte (qt, kb): bit w = some (``every``: every in-range) position allowed in queries 32 qt .. x keys 128 kb + 16 w ..
+    (include/npm_hip.h)"""
+    nb, nh, sq, skv = full.shape
+    nqt, nkb = (sq + 31) // 32, (skv + 127) // 128
+    out = np.zeros([nb, nh, nqt, nkb], dtype=np.uint8)
+    for qt in range(nqt):
+        for kb in range(nkb):
+            for w in range(8):
+                sub = full[:, :, 32 * qt:32 * qt + 32, 128 * kb + 16 * w:128 * kb + 16 * w + 16]
+                if sub.size:
+                    out[:, :, qt, kb] |= ((sub.all(axis=(2, 3)) if every else sub.any(axis=(2, 3))).astype(np.uint8) << w)
+    return out
+
+
+def test_mask_summary(npm):
+    """npm_mha_mask_summary against NumPy: dense, broadcast (batch / head / query) and ragged masks."""
+    from np_modeling_amd import device as D
+    rng = np.random.default_rng(0)
+    for shape, (b, h, sq, skv) in (([2, 3, 70, 300], (2, 3, 70, 300)), ([1, 1, 129, 129], (4, 2, 129, 129)),
+                                   ([1, 2, 1, 200], (3, 2, 50, 200)), ([2, 1, 33, 16], (2, 5, 33, 16))):
+        mask = rng.random(shape) < 0.02
+        mask[..., :40, 130:] = False
+        mask[..., 160:] |= rng.random(shape[:2] + [1, 1]) < 0.5          # ... and whole sub-tiles without an excluded position
+        dev = D.AttnMask(mask, b, h, sq, skv)
+        assert dev.summary is not None
+        nb, nh = shape[0], shape[1]
+        full = np.broadcast_to(mask, (nb, nh, sq, skv))
+        got = dev.summary.numpy().reshape(2, nb, nh, (sq + 31) // 32, (skv + 127) // 128)
+        np.testing.assert_array_equal(got[0], _summary_numpy(full))
+        np.testing.assert_array_equal(got[1], _summary_numpy(full, every=True))
+        assert dev.summary_all_offset == got[0].size
+        assert dev.summary_strides == (0 if nb == 1 else got[0, 0].size, 0 if nh == 1 else got[0, 0, 0].size)
+
+
+@pytest.mark.parametrize('d', [16, 64, 128])
+@pytest.mark.parametrize('kind', ['causal', 'band', 'blocks', 'sparse', 'cross'])
+def test_core_tile_skipping_changes_nothing(npm, d, kind, bwd_kernel):
+    """With the mask's tile summary the kernels skip tiles (and, inside a tile, waves) that have no allowed position: results are
+    BIT-equal to the unskipped run -- a skipped tile only ever added zeros -- and match the oracle; saved scores inside skipped
+    tiles stay unwritten.  Masks with many empty tiles: causal, a narrow band, block-diagonal, 2 % random, and a cross-attention
+    shape whose first key block is hidden from most queries."""
+    rng = np.random.default_rng(d + len(kind))
+    b, h, sq, skv = (2, 2, 288, 300) if kind != 'cross' else (1, 2, 200, 400)
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k, v = (rng.standard_normal([b, skv, h, d]).astype(np.float32) for _ in range(2))
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    i, j = np.arange(sq)[:, None], np.arange(skv)[None, :]
+    mask = {'causal': (j <= i)[None, None], 'band': ((j <= i) & (j >= i - 20))[None, None],
+            'blocks': ((i // 96) == (j // 96))[None, None],
+            'sparse': np.where(rng.random([b, h, sq, skv]) < 0.02, True, j == (i * 7) % skv),
+            'cross': ((j >= 130) | (i < 20))[None, None]}[kind]
+    full = np.broadcast_to(mask, (b, h, sq, skv))
+    assert full.any(axis=-1).all()                                  # every query keeps a key: no NaN rows
+    assert (_summary_numpy(full) == 0).any() or kind == 'sparse'    # ... and whole tiles are empty
+    ctx, lse, probs = O.attention_core_fwd(*(x.astype(np.float64) for x in (q, k, v)), scale, full)
+    dq, dk, dv = O.attention_core_bwd(*(x.astype(np.float64) for x in (q, k, v)), probs, dctx.astype(np.float64), scale)
+    for save in (False, True):
+        got = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save)
+        plain = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save, skip=False)
+        # (the default choice runs head size 128 with saved scores on mha_bwd16_kernel when there is NO summary and on
+        # mha_bwd8_kernel when there is one: two kernels, equal to rounding only)
+        same_kernel = not (bwd_kernel == 2 and d == 128 and save)
+        # (bit equality needs whole query tiles: a tile without excluded positions runs WITHOUT the mask, so the idle lanes of a
+        # ragged last tile -- queries beyond seq_q -- carry scores of 0 instead of -inf, and the wave-wide decision when to move the
+        # softmax's reference point can fall differently: the 'cross' shape ends in 8 of 32 rows and is compared to rounding)
+        for name in ('ctx', 'lse', 'dq', 'dk', 'dv'):
+            if sq % 32:
+                assert_close(got[name], plain[name], tol=5e-7, what=f'{kind} {name} save={save}')
+            elif same_kernel or name in ('ctx', 'lse'):
+                np.testing.assert_array_equal(got[name], plain[name], err_msg=f'{kind} {name} save={save}')
+        assert_close(got['ctx'], ctx, tol=2e-6, what=kind)
+        for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+            assert_close(got[name], want, tol=3e-6, what=f'{kind} {name} save={save}')
+        if save and bwd_kernel >= 2:
+            raw = np.einsum('bqhd,bkhd->bhqk', q.astype(np.float64), k.astype(np.float64))
+            written = got['scores'] != 777.0
+            assert written[full].all()                              # every allowed position was stored ...
+            assert_close(np.where(full, got['scores'], 0), np.where(full, raw, 0), tol=2e-6)
+            if kind != 'sparse':
+                assert (~written).any()                             # ... and whole tiles were not
+
+
+def test_core_query_tile_without_any_key(npm):
+    """A whole 32-query tile whose rows have no key at all: no key block visits it.  Forward: those rows are NaN (the softmax
+    of a row of -inf), the others exact; backward: their dq rows are ZERO (filled at the end) and, unlike the unskipped run,
+    they do not poison dk / dv."""
+    rng = np.random.default_rng(5)
+    b, h, sq, skv, d = 1, 2, 96, 160, 128
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k, v = (rng.standard_normal([b, skv, h, d]).astype(np.float32) for _ in range(2))
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    mask = np.ones([b, h, sq, skv], dtype=bool)
+    mask[:, :, 32:64, :] = False
+    scale = 1.0 / np.sqrt(d)
+    keep = np.ones(sq, dtype=bool)
+    keep[32:64] = False
+    sub = [x.astype(np.float64) for x in (q[:, keep], k, v)]
+    ctx, lse, probs = O.attention_core_fwd(*sub, scale)
+    dq, dk, dv = O.attention_core_bwd(*sub, probs, dctx[:, keep].astype(np.float64), scale)
+    for save in (False, True):
+        got = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save)
+        assert np.isnan(got['ctx'][:, ~keep]).all()
+        assert_close(got['ctx'][:, keep], ctx, tol=2e-6)
+        from np_modeling_amd import _C
+        if _C.last_attn_kernel().startswith('mha_bwd8_kernel'):
+            np.testing.assert_array_equal(got['dq'][:, ~keep], 0.0)
+            assert_close(got['dq'][:, keep], dq, tol=3e-6)
+            assert_close(got['dk'], dk, tol=3e-6)
+            assert_close(got['dv'], dv, tol=3e-6)
 
 
 def test_core_row_without_any_key_is_nan_and_only_that_row(npm):

@@ -1,8 +1,10 @@
 """GPU: the product's layers against the REFERENCE'S OWN OUTPUTS at the reference's own test shapes and at every head size
 the fused attention kernels take (tests/golden/ref_*.npz; recipes and rationale in tests/refshapes.py).  In the default
 exact-f32 arithmetic the tests assert that the fused kernels are what ran (npm_last_attn_kernel / npm_last_math), so
-mha_fwd_kernel, mha_bwd16_kernel (head size 128, saved scores) and mha_bwd_kernel (the other head sizes, and the
-recomputing mode) are compared with reference arrays directly, not through the oracle."""
+mha_fwd_kernel, mha_bwd16_kernel (head size 128 with saved scores: the BASELINE configs' path) and mha_bwd8_kernel (every
+other head size, and the recomputing mode) are compared with reference arrays directly, not through the oracle; the other
+choices of NPM_TUNE_ATTN_BWD16 (3: mha_bwd8_kernel always; 1 / 0: round 3's kernels) run the same fixtures in
+test_reference_outputs_other_backward_kernels."""
 
 import numpy as np
 import pytest
@@ -38,10 +40,30 @@ def test_reference_outputs(npm, name, math_mode):
     def after_backward(layer):
         if fused:
             last = npm._C.last_attn_kernel()
-            assert last == (f'mha_bwd16_kernel D={d} mask=0 scores=1' if d == 128 else f'mha_bwd_kernel D={d} mask=0 scores=1'), last
+            assert last == f'{"mha_bwd16_kernel" if d == 128 else "mha_bwd8_kernel"} D={d} mask=0 scores=1', last
 
     got, ref = RR.run(npm, name, after_forward, after_backward)
     RR.compare(got, ref, tol=1e-5)
+
+
+@pytest.mark.parametrize('name', [n for n in ATTENTION if R.CASES[n]['kind'] == 'mha'])
+@pytest.mark.parametrize('knob', [3, 1, 0])
+def test_reference_outputs_other_backward_kernels(npm, name, knob):
+    """The other choices of NPM_TUNE_ATTN_BWD16 stay selectable and run the same fixtures: 3 = mha_bwd8_kernel always,
+    1 = mha_bwd16_kernel (head size 128) / the 4-wave mha_bwd_kernel, 0 = the 4-wave kernel."""
+    from np_modeling_amd import _C
+    d = R.CASES[name]['feat'] // R.CASES[name]['heads']
+    want = 'mha_bwd8_kernel' if knob == 3 else ('mha_bwd16_kernel' if (knob == 1 and d == 128) else 'mha_bwd_kernel')
+    _C.check(_C.lib().npm_set_tuning(14, knob), 'npm_set_tuning')
+    try:
+        got, ref = RR.run(npm, name, after_backward=lambda layer: _assert_kernel(npm, f'{want} D={d} mask=0 scores=1'))
+    finally:
+        _C.check(_C.lib().npm_set_tuning(14, 2), 'npm_set_tuning')
+    RR.compare(got, ref, tol=1e-5)
+
+
+def _assert_kernel(npm, want):
+    assert npm._C.last_attn_kernel() == want, npm._C.last_attn_kernel()
 
 
 @pytest.mark.parametrize('name', [n for n in ATTENTION if R.CASES[n]['kind'] == 'mha'])
@@ -58,7 +80,7 @@ def test_reference_outputs_recomputing_backward(npm, name):
             assert npm._C.last_attn_kernel() == f'mha_fwd_kernel D={d} mask=0 scores=0'
 
         def after_backward(layer):
-            assert npm._C.last_attn_kernel() == f'mha_bwd_kernel D={d} mask=0 scores=0'
+            assert npm._C.last_attn_kernel() == f'mha_bwd8_kernel D={d} mask=0 scores=0'
 
         got, ref = RR.run(npm, name, after_forward, after_backward)
     finally:
