@@ -602,8 +602,8 @@ mha_bwd_kernel(const MhaArgs p) {
         for (int qt = 0; qt < nqt; ++qt) {
             // Tile qt (and the K block) has landed for every wave; the other stage and sDS are free.  The dQ stores
             // of the previous tile are the youngest 4 vector-memory operations of this wave: they stay in flight.
-            if (in_flight == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (in_flight == 36) asm volatile("s_waitcnt vmcnt(36)" ::: "memory");
+            if (in_flight == 4) asm volatile("s_waitcnt vmcnt(4) ; npm:wait" ::: "memory");
+            else if (in_flight == 36) asm volatile("s_waitcnt vmcnt(36) ; npm:wait" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -843,15 +843,14 @@ mha_bwd16_kernel(const MhaArgs p) {
     using T = Tile<D>;
     constexpr int QTILE = 32 * D, KBLK = 128 * D, ROWS16 = 16 * D;         // floats
     // one __shared__ object, pieces issued from inline assembly (see mha_bwd_kernel)
-    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + 32 * 128 + 8 * 64];
-    float *const sKB = smem, *const sQ = sKB + KBLK, *const sDO = sQ + 2 * QTILE, *const sDS = sDO + 2 * QTILE, *const sRow = sDS + 32 * 128;
+    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + 32 * 128];
+    float *const sKB = smem, *const sQ = sKB + KBLK, *const sDO = sQ + 2 * QTILE, *const sDS = sDO + 2 * QTILE;
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0 .. 7
     const int l16 = lane & 15, kk = lane >> 4;
     const int bh = blockIdx.x;
     const int b = bh / p.heads, h = bh - b * p.heads;
-    float *xs = sRow + wave * 64;
 
     const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
     const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
@@ -861,8 +860,10 @@ mha_bwd16_kernel(const MhaArgs p) {
     const auto rsrcDK = make_rsrc(p.dk + (long)b * p.seq_kv * p.dk_pitch + h * D, ((long)(p.seq_kv - 1) * p.dk_pitch + D) * 4);
     const auto rsrcDV = make_rsrc(p.dv + (long)b * p.seq_kv * p.dv_pitch + h * D, ((long)(p.seq_kv - 1) * p.dv_pitch + D) * 4);
     const auto rsrcNone = make_rsrc(p.dq, 0);
-    const auto rsrcL = make_rsrc(p.lse + (long)bh * p.seq_q, (long)p.seq_q * 4);
-    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.seq_q, (long)p.seq_q * 4);
+    // row terms (mha_rowterms_kernel): log2(e) LSE and MINUS delta, padded to whole tiles and finite in the padding, so that a
+    // lane's four consecutive queries are one 16-byte load each -- no staging through LDS, no multiply, no exec-masked writes
+    const auto rsrcL = make_rsrc(p.lse2 + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
+    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
     const auto rsrcS = make_rsrc(p.scores + (long)bh * p.seq_q * p.seq_kv, (long)p.seq_q * p.seq_kv * 4);
     const int srow_bytes = p.seq_kv * 4;
 
@@ -907,10 +908,18 @@ mha_bwd16_kernel(const MhaArgs p) {
     }
     dma_group<2>(descQ, lds_q, 0u, vq);
     dma_group<2>(descDO, lds_do, 0u, vdo);
-    float lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, (lane & 31) * 4, 0, 0));
-    float dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, (lane & 31) * 4, 0, 0));
-    if (lane < 32) { xs[lane] = lse_n * LOG2E; xs[32 + lane] = dlt_n; }
 
+    f32x4 Lr_n[2], Dr_n[2];
+    auto load_rows = [&](int qfirst) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const u32x4_t l4 = __builtin_amdgcn_raw_buffer_load_b128(rsrcL, 16 * kk, (qfirst + 16 * t) * 4, 0);
+            const u32x4_t d4 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDl, 16 * kk, (qfirst + 16 * t) * 4, 0);
+            Lr_n[t] = f32x4{__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
+            Dr_n[t] = f32x4{__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
+        }
+    };
+    load_rows(0);
     for (int kb = 0; kb < nkb; ++kb) {
         const int kvrow = kb * 128 + kvl;
         const bool kvok = kvrow < p.seq_kv;
@@ -922,8 +931,8 @@ mha_bwd16_kernel(const MhaArgs p) {
         int in_flight = kb > 0 ? 18 : 0;                 // youngest vector-memory operations that may stay outstanding
 
         for (int qt = 0; qt < nqt; ++qt) {
-            if (in_flight == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (in_flight == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+            if (in_flight == 2) asm volatile("s_waitcnt vmcnt(2) ; npm:wait" ::: "memory");
+            else if (in_flight == 18) asm volatile("s_waitcnt vmcnt(18) ; npm:wait" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -933,16 +942,11 @@ mha_bwd16_kernel(const MhaArgs p) {
             const int cur = it & 1, nxt = cur ^ 1;
             const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
             const int q0 = 32 * qt;
-            // row terms of this tile: queries 16 t + 4 kk + r in the registers
+            // row terms of this tile (queries 16 t + 4 kk + r in the registers): requested a tile ago; the next tile's now
             f32x4 Lr[2], Dr[2];
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
-                const float4 l4 = ld4(xs + 16 * t + 4 * kk), d4 = ld4(xs + 32 + 16 * t + 4 * kk);
-                Lr[t] = f32x4{l4.x, l4.y, l4.z, l4.w};
-                Dr[t] = f32x4{d4.x, d4.y, d4.z, d4.w};
-            }
-            lse_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcL, (lane & 31) * 4, 32 * nq * 4, 0));
-            dlt_n = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcDl, (lane & 31) * 4, 32 * nq * 4, 0));
+            for (int t = 0; t < 2; ++t) { Lr[t] = Lr_n[t]; Dr[t] = Dr_n[t]; }
+            load_rows(32 * nq);
             // raw scores of this tile (nontemporal: read once) and the old dQ values (the dQ accumulators start from them)
             f32x4 S[2], acc[2];
 #pragma unroll
@@ -958,7 +962,8 @@ mha_bwd16_kernel(const MhaArgs p) {
             }
 
             // ---- dP[q, kv] = dO V^T: 8 steps of (2 row reads, 8 MFMAs), reads one step ahead
-            f32x4 dP[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+            // (the accumulators start from -delta, which has their layout: no zeroing, no subtraction afterwards)
+            f32x4 dP[2] = {Dr[0], Dr[1]};
             float4 fa[2][2];
             fa[0][0] = ld4(tDO + rb[0]);
             fa[0][1] = ld4(tDO + rb[0] + ROWS16);
@@ -986,7 +991,7 @@ mha_bwd16_kernel(const MhaArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const float pr = fast_exp2(fmaf(S[t][r], c, -Lr[t][r]));
                     P[t][r] = pr;
-                    dS[t][r] = pr * (dP[t][r] - Dr[t][r]);
+                    dS[t][r] = pr * dP[t][r];
                     sDS[ws[r] + t * ROWS16] = dS[t][r];
                 }
             // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (2 vector reads, 8 MFMAs)
@@ -1074,8 +1079,6 @@ mha_bwd16_kernel(const MhaArgs p) {
                 dK[6] = MFMA16(e1.z, dS[t][r], dK[6]); dK[7] = MFMA16(e1.w, dS[t][r], dK[7]);
                 FENCE();
             }
-            // the next tile's row terms (requested at the top of this one) go to LDS now
-            if (lane < 32) { xs[lane] = lse_n * LOG2E; xs[32 + lane] = dlt_n; }
             in_flight = 2;
             ++it;
             FENCE();
@@ -1309,7 +1312,7 @@ mha_bwd8_kernel(const MhaArgs p) {
             const bool last = nxt < 0;                                           // last tile of this key block
             const int nq = !last ? nxt : (kb + 1 < nkb ? first_tile(act_n) : -1);   // the tile whose Q / dO pieces go out in this one
             // ---- the tile's pieces (and, at a seam, the K block) have landed for every wave; dS of the pending tile is in LDS
-            if (n_inflight == 2 * NC) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * NC) : "memory");
+            if (n_inflight == 2 * NC) asm volatile("s_waitcnt vmcnt(%0) ; npm:wait" :: "n"(2 * NC) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1694,12 +1697,11 @@ int launch_bwd(const MhaArgs &a, hipStream_t s) {
     // Saved scores already CARRY the mask (the forward stored -inf at every masked position, so P = exp2(-inf) = 0
     // there): the backward needs the mask bytes only when it recomputes q.k.  One instance less per head size -- the
     // one whose 16 extra byte loads per tile did not fit the register file at D = 128.
-    const bool wide = saved && D == 128 && (g_attn_bwd16 == 1 || g_attn_bwd16 == 2) && !a.trace;
-    if (wide) hipLaunchKernelGGL(mha_bwd16_kernel, dim3(grid), dim3(512), 0, s, a);
-    else if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
+    // (mha_bwd16_kernel and mha_bwd8_kernel are launched by npm_mha_core_bwd itself: they take the padded row terms)
+    if (saved) launch_bwd_instance<D, false, true>(a, grid, s);
     else if (mask) launch_bwd_instance<D, true, false>(a, grid, s);
     else launch_bwd_instance<D, false, false>(a, grid, s);
-    note_kernel(wide ? "mha_bwd16_kernel" : "mha_bwd_kernel", D, mask && !saved, saved);
+    note_kernel("mha_bwd_kernel", D, mask && !saved, saved);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }
@@ -1818,7 +1820,9 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
     }
     npm::Scratch ws;                                  // stream-ordered pool: safe to release when this call returns
     const bool wide128 = c->head_dim == 128 && a.scores != nullptr && a.skip == nullptr;      // the case mha_bwd16_kernel was built for
-    if ((g_attn_bwd16 == 3 || (g_attn_bwd16 == 2 && !wide128)) && !a.trace) {
+    const bool use8 = (g_attn_bwd16 == 3 || (g_attn_bwd16 == 2 && !wide128)) && !a.trace;
+    const bool use16 = !use8 && wide128 && (g_attn_bwd16 == 1 || g_attn_bwd16 == 2) && !a.trace;
+    if (use8 || use16) {
         // mha_bwd8_kernel: row terms padded to whole query tiles ([B, H, sq_pad] each: delta, then log2(e) LSE)
         a.sq_pad = (a.seq_q + 31) / 32 * 32;
         const long padded = (long)a.batch * a.heads * a.sq_pad;
@@ -1832,6 +1836,12 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
                            (long)a.sq_pad, a.heads, c->head_dim, a.scale);
         NPM_CHECK_LAUNCH();
         npm::note_math(NPM_MATH_F32);
+        if (use16) {
+            hipLaunchKernelGGL(mha_bwd16_kernel, dim3(a.batch * a.heads), dim3(512), 0, s, a);
+            note_kernel("mha_bwd16_kernel", 128, false, true);
+            NPM_CHECK_LAUNCH();
+            return NPM_OK;
+        }
         switch (c->head_dim) {
             case 16: return launch_bwd8<16>(a, s);
             case 32: return launch_bwd8<32>(a, s);

@@ -592,7 +592,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
         /* tile KT is in LDS for every wave (the DMA pieces: vmcnt; the masked rows: lgkmcnt); the other stage is   \
            free.  The g stores of the tile before are this wave's youngest vector-memory operations: they stay in  \
            flight. */                                                                                              \
-        if (stored) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
+        if (stored) asm volatile("s_waitcnt vmcnt(2) ; npm:wait" ::: "memory");                                    \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
         __builtin_amdgcn_s_barrier();                                                                              \

@@ -276,7 +276,7 @@ sgemm_glds_kernel(const GemmArgs p) {
     } else {
         int stage = 0;
         for (int kt = 0; kt < nkt; ++kt) {
-            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(A_PW + B_PW) : "memory");
+            if (kt + 1 < nkt) asm volatile("s_waitcnt vmcnt(%0) ; npm:wait" ::"n"(A_PW + B_PW) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");

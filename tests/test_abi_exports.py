@@ -144,3 +144,22 @@ def test_no_kernel_spills_vector_registers(built):
     attn = kernel_meta.kernel_metadata(os.path.join(lib_dir, 'npm_attn.o'))
     assert not any('mha_bwd_kernel<128, true, true' in name for name in attn)
     assert any('mha_bwd_kernel<128, true, false' in name for name in attn)
+
+
+def test_hand_counted_waits_match_the_pinned_disassembly():
+    """The LDS-DMA pipelines of the attention backward kernels, the fused Conv2D filter gradient and the three-stage GEMM
+    order their pieces with hand-written `s_waitcnt vmcnt(N)`; N counts COMPILER-emitted loads and stores, so a toolchain
+    that emits them differently makes a wait too lax without failing a parity test.  tools/waitcnt_check.py reduces every
+    such kernel to the order of its DMA pieces, loads, stores, tagged waits and barriers and compares with the signatures
+    (and the compiler version) the counts were validated on (tools/waitcnt_pins.json)."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    import waitcnt_check
+    with open(waitcnt_check.PINS) as f:
+        pinned = json.load(f)
+    now = waitcnt_check.current()
+    problems = waitcnt_check.compare(now, pinned)
+    assert not problems, 'hand-counted vmcnt waits need re-validation (tools/waitcnt_check.py):\n' + '\n'.join(problems)
+    tagged = sum(sig.count('W') for sig in now['kernels'].values())
+    assert tagged >= 40 and any('mha_bwd16_kernel' in k for k in now['kernels'])
