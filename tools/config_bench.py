@@ -202,8 +202,34 @@ def cpu_baseline(name, budget_s=10.0):
         step()
         times.append(time.perf_counter() - t0)
     best = min(times)
-    return {'value': b / best, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
-            'sample': f'NumPy oracle: {sample}; best of {len(times)} steps ({best:.2f} s/step)'}
+    out = {'value': b / best, 'unit': 'samples/s', 'cores': os.cpu_count(), 'kind': 'port',
+           'sample': f'NumPy oracle: {sample}; best of {len(times)} steps ({best:.2f} s/step)'}
+    if name == 'C4':
+        # Line (1) of BASELINE.md section 3 for this config: the reference's OWN formulation (np.einsum contractions -- single-
+        # threaded C loops, no BLAS -- and the explicit [rows, n, n] fp64 softmax Jacobian, attentions.py:67-199 with
+        # activations.py:32-45), restated verbatim by the oracle.  Its temporaries grow with seq^3 (2.2 TB at the full shape), so
+        # the sample is ONE sequence of 128 tokens at the full width; quoted as tokens/s and, divided by 512, as the samples/s a
+        # full-length sample could at best reach.
+        sv = 128
+        qv = rng.standard_normal([1, sv, f], dtype=np.float32)
+        dv = rng.standard_normal([1, sv, f], dtype=np.float32) * np.float32(0.01)
+        t0 = time.perf_counter()
+        _, cache = O.mha_fwd(p, qv, verbatim=True)
+        _, grads = O.mha_bwd(p, cache, dv, verbatim=True)
+        for k in p:
+            O.sgd_step(p[k], grads[k], 1e-6)
+        tv = time.perf_counter() - t0
+        out['reference_verbatim'] = {
+            'value': sv / tv / s, 'unit': 'samples/s', 'tokens_per_s': sv / tv, 'cores': 1, 'kind': 'port',
+            'sample': f'reference-verbatim formulation (einsum contractions, fp64 softmax Jacobian) MultiHeadAttention fwd+bwd+SGD, '
+                      f'1 x seq {sv} x d {f}, one step ({tv:.1f} s); samples/s = tokens/s / {s} (an upper bound: the Jacobian grows '
+                      'with seq^3)'}
+    elif name == 'C3':
+        out['reference_verbatim'] = {'same_as': 'the line above: the oracle\'s Conv2D IS the reference\'s formulation (fp64 padded copy, '
+                                                'k*k shifted matmuls, conv.py:97-105,185-194), only run on a batch that fits'}
+    elif name == 'C2':
+        out['reference_verbatim'] = {'same_as': 'the line above: Dense is np.matmul in the reference too (mlp.py:23,35,36)'}
+    return out
 
 
 def main():
@@ -231,6 +257,9 @@ def main():
         if args.cpu:
             c = cpu_baseline(name)
             print(f"    cpu_baseline: {c['value']:.3f} samples/s on {c['cores']} cores -- {c['sample']}", flush=True)
+            rv = c.get('reference_verbatim', {})
+            if 'value' in rv:
+                print(f"    reference-verbatim: {rv['value']:.4f} samples/s on {rv['cores']} core -- {rv['sample']}", flush=True)
 
 
 if __name__ == '__main__':

@@ -6,7 +6,7 @@
 # the decoder line, the HBM-side probe and the TCC request counters of the weight-gradient GEMM.
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-R=${NPM_ROUND:-r03}
+R=${NPM_ROUND:-r04}
 OUT=$REPO/gpurun_out/profiles_new
 mkdir -p "$OUT"
 cd "$REPO"
@@ -15,12 +15,17 @@ echo "== clock / power during 60 steps"; tools/clock_sampler.sh "$OUT/clocks_f32
 { echo "bench.py --steps 60 --warmup 3, sysfs freq1_input / power1_input of the loaded card (tools/clock_sampler.sh)";
   echo "math f32: $(python3 -c "import json;d=json.load(open('$OUT/bench_60.json'));print(round(d['value'],1),'samples/s',round(d['ms_per_step'],2),'ms/step')")  $(python3 tools/clock_summary.py $OUT/clocks_f32.log)"; } > "$OUT/${R}_clock_power.log"
 echo "== config bench (f32)"; { timeout -k 10 300 python tools/config_bench.py --kernels --cpu; echo "-- TransformerDecoder at size (not a BASELINE config)"; timeout -k 10 200 python tools/config_bench.py --only DEC --kernels;
-  echo "-- C3 with the two-pass ReLU backward (NPM_TUNE 13=0) and with 128-row tiles (13=2), for comparison"; NPM_TUNE=13=0 timeout -k 10 200 python tools/config_bench.py --only C3 --kernels; NPM_TUNE=13=2 timeout -k 10 200 python tools/config_bench.py --only C3 --kernels; } > "$OUT/${R}_config_bench.log" 2>&1
+  echo "-- C3 with the K loop of forward / grad_x by taps (NPM_TUNE 16=0: round 3) and by 16-channel chunks (16=1: default), alternating"; for k in 0 1 0 1; do echo "NPM_TUNE=16=$k"; NPM_TUNE=16=$k timeout -k 10 200 python tools/config_bench.py --only C3 --kernels; done; } > "$OUT/${R}_config_bench.log" 2>&1
 echo "== gemm shapes (f32)"; timeout -k 10 200 python tools/gemm_bench.py --tune 10=0 > "$OUT/${R}_gemm_shapes.log" 2>&1
 echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/${R}_rowops.log" 2>&1
-echo "== fused attention core"; { timeout -k 10 100 python tools/attn_bench.py; timeout -k 10 100 python tools/attn_bench.py --save-scores;
-  echo "-- masked (causal, then random per (b, h)), scores saved (the default) and recomputed"; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal; timeout -k 10 100 python tools/attn_bench.py --mask causal; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask random;
-  echo "-- stamps, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved (the default)"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
+echo "== fused attention core"; { echo "-- saved scores (the default), then recomputing; --reps 12: the card needs a few launches to settle";
+  timeout -k 10 100 python tools/attn_bench.py --save-scores --reps 12; timeout -k 10 100 python tools/attn_bench.py --reps 12;
+  echo "-- the same with mha_bwd8_kernel for everything (NPM_TUNE 14=3), and with round 3's backward kernels (14=1)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --reps 12 --tune 14=3; timeout -k 10 100 python tools/attn_bench.py --reps 12 --tune 14=1;
+  echo "-- head sizes 64 / 32 / 16 (H x D = 1024), saved scores: default (mha_bwd8_kernel) and round 3's 4-wave backward (14=1)";
+  for d in 64 32 16; do timeout -k 10 100 python tools/attn_bench.py --save-scores --d $d --h $((1024 / d)) --reps 8; timeout -k 10 100 python tools/attn_bench.py --save-scores --d $d --h $((1024 / d)) --reps 8 --tune 14=1; done;
+  echo "-- masked (causal, then random per (b, h)), scores saved (the default) and recomputed; then causal WITHOUT the tile summary (NPM_ATTN_TILE_SKIP=0)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --reps 12; timeout -k 10 100 python tools/attn_bench.py --mask causal --reps 12; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask random --reps 8; NPM_ATTN_TILE_SKIP=0 timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --reps 12;
+  echo "-- masks of different shapes, saved scores (forward / backward of the 4th repetition)"; timeout -k 10 100 python tools/attn_masks.py;
+  echo "-- stamps of the 4-wave kernels, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
 echo "== parity report (f32)"; timeout -k 10 600 python -c "import sys; sys.path.insert(0, 'tools'); import parity_report; parity_report.main(modes=('f32',))" > "$OUT/${R}_parity_relative_error.log" 2>&1
 echo "== exchange path on one GPU: bench.py without and with a one-rank RCCL communicator (NPM_FORCE_RCCL=1)"
 { echo "bench.py --steps 30 --warmup 5 --no-alt-math --no-configs --no-cpu-baseline, alternating; exchange = rank 0's HIP-event statistics per step";
@@ -48,7 +53,13 @@ cd "$REPO"
 python3 profiles/summarize_pmc.py "$OUT"/pmc_FETCH_SIZE/*/*_counter_collection.csv "$OUT"/pmc_WRITE_SIZE/*/*_counter_collection.csv > "$OUT/pmc_traffic.json"
 echo "== TCC request counters of the FFN weight-gradient GEMM (DRAM-destined vs all; L2 hit / miss)"
 tools/pmc/one_shape.sh "ffn_dw_TN M=1024" 10=0 "$OUT/pmc_tn" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RD_UNCACHED_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" > "$OUT/${R}_pmc_tcc_ffn_dw.log" 2>&1
-echo "== SQ counters: fused attention"
-tools/pmc/attn.sh "$OUT/pmc_attn" --save-scores > "$OUT/${R}_pmc_attn_core.log" 2>&1
-rm -rf "$OUT"/prof "$OUT"/prof_cfg "$OUT"/prof_dec "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_tn "$OUT"/pmc_attn
+echo "== SQ / TCC counters of the kernels that are in the step and in the configs"
+{ echo "# tools/pmc/groups.sh: one rocprofv3 --pmc process per counter group, last launch of each kernel"; echo "### attention, C4 shape, saved scores (the default: mha_fwd_kernel, mha_rowterms_kernel, mha_bwd16_kernel)"; tools/pmc/groups.sh "$OUT/pmc_a1" 'mha_' sq -- tools/attn_bench.py --reps 2 --save-scores; echo "### the same under NPM_TUNE 14=3 (mha_bwd8_kernel)"; tools/pmc/groups.sh "$OUT/pmc_a2" 'mha_bwd' sq -- tools/attn_bench.py --reps 2 --save-scores --tune 14=3; } > "$OUT/${R}_pmc_attn_sq.log" 2>&1
+{ echo "### attention, C4 shape, saved scores: L2 requests that leave the XCD"; tools/pmc/groups.sh "$OUT/pmc_a3" 'mha_' tcc -- tools/attn_bench.py --reps 2 --save-scores; } > "$OUT/${R}_pmc_attn_tcc.log" 2>&1
+{ for shp in "ffn1_NN" "ffn_dx_NT M=131072 N=1024" "ffn_dw_TN M=1024"; do echo "### gemm_bench --only '$shp'"; tools/pmc/groups.sh "$OUT/pmc_g" 'sgemm_glds' sq -- tools/gemm_bench.py --only "$shp" --reps 2 --tune 10=0; rm -rf "$OUT/pmc_g"; done; } > "$OUT/${R}_pmc_gemm_sq.log" 2>&1
+{ echo "### config_bench --only C3 (conv_fwd_glds_kernel<false> = forward, <true> = grad_x, conv_wgrad_relu_kernel)"; tools/pmc/groups.sh "$OUT/pmc_c1" 'conv_' sq -- tools/config_bench.py --only C3 --min-seconds 0.05; } > "$OUT/${R}_pmc_conv_sq.log" 2>&1
+{ echo "### config_bench --only C3, K loop by 16-channel chunks (default)"; tools/pmc/groups.sh "$OUT/pmc_c2" 'conv_' tcc -- tools/config_bench.py --only C3 --min-seconds 0.05; echo "### ... by taps (NPM_TUNE=16=0, round 3)"; NPM_TUNE=16=0 tools/pmc/groups.sh "$OUT/pmc_c3" 'conv_fwd' "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum;TCC_HIT_sum TCC_MISS_sum" -- tools/config_bench.py --only C3 --min-seconds 0.05; } > "$OUT/${R}_pmc_conv_tcc.log" 2>&1
+echo "== GEMM timeline"; { for a in "1024" "4096" "131072 4096 1024" "131072 128 576" "c2" "qk"; do echo "### gemm_trace.py $a"; timeout -k 10 120 python tools/gemm_trace.py $a; done; } > "$OUT/${R}_gemm_timeline.log" 2>&1
+echo "== the reference's own assertion form"; timeout -k 10 300 python tools/reference_form_report.py > "$OUT/${R}_reference_form.md" 2> "$OUT/refform.err"
+rm -rf "$OUT"/prof "$OUT"/prof_cfg "$OUT"/prof_dec "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_tn "$OUT"/pmc_attn "$OUT"/pmc_a1 "$OUT"/pmc_a2 "$OUT"/pmc_a3 "$OUT"/pmc_g "$OUT"/pmc_c1 "$OUT"/pmc_c2 "$OUT"/pmc_c3
 echo "== done"; ls "$OUT"
