@@ -12,6 +12,10 @@
  *   - One process drives one GPU: npm_init(device) binds the process to a device and
  *     creates the compute stream all launches go to.  Launches are asynchronous;
  *     npm_sync() / npm_d2h() are the synchronisation points.
+ *   - ONE host thread per process: the library keeps process-global state (the device, its one compute
+ *     stream, the caching pool, the math mode and tuning knobs, npm_last_error / npm_last_math /
+ *     npm_last_attn_kernel) without locks.  Calls from several threads must be serialised by the caller;
+ *     parallelism across GPUs is one process per GPU (np_modeling_amd/launch.py, include/npm_comm.h).
  *   - All tensors are fp32, row-major; "ld" is the row pitch in elements.
  *   - Device pointers come from npm_malloc (a stream-ordered caching pool).
  */
