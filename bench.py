@@ -405,6 +405,12 @@ def main():
             if not args.no_cpu_baseline:
                 entry['cpu_baseline'] = config_bench.cpu_baseline(name)
             result['configs'][name] = entry
+        # two more lines beside the BASELINE configs (no CPU baseline; not BASELINE.json's): C4 under a causal mask -- the mask's tile
+        # summary lets the fused kernels skip empty tiles -- and C4's dimensions with 16 heads of 64 (the 8-wave backward at head size 64)
+        result['configs_extra'] = {}
+        for name in ('C4M', 'C4D64'):
+            result['configs_extra'][name] = config_bench.run_config(name, npm, D, min_seconds=args.configs_min_seconds)
+            D.trim_pool()
     if comm.active:
         comm.barrier()                                   # every timed region of every rank is over
     D.synchronize()

@@ -674,6 +674,7 @@ class AttnMask:
     stride 0.  ``np.where(mask, scaled, -inf)`` of reference layers/attentions.py:105-107."""
 
     def __init__(self, mask, b: int, h: int, sq: int, skv: int):
+        self.dims = (int(b), int(h), int(sq), int(skv))
         host = np.asarray(mask).astype(bool)
         while host.ndim < 4:
             host = host[None]

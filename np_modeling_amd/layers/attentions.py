@@ -23,7 +23,9 @@ one element, and its backward raises NotImplementedError (attentions.py:152-153)
 there.  This layer implements the evident intent instead: ``mask`` is a boolean array broadcastable to
 [B, H, Sq, Skv]; excluded positions get ``-inf`` before the softmax (``np.where(mask, scaled, -inf)``) and
 probability exactly 0, in forward and backward; a query row with no position left yields NaN, as that ``np.where``
-followed by the reference's softmax would.
+followed by the reference's softmax would.  A ``device.AttnMask`` made once (``AttnMask(mask, B, H, Sq, Skv)``) may be
+passed instead of the array: its bytes and its tile summary (which lets the kernels skip tiles without an allowed
+position) then stay on the device between steps.
 
 Parameter layouts are the reference's: wq/wk [H, Dk, H*Dk], wv [H, Dv, H*Dv], wo [H*Dk, H, Dv],
 bq/bk [H, Dk], bv [H, Dv], bo [H*Dk] (attentions.py:46-65), drawn in that order.
@@ -121,9 +123,13 @@ class MultiHeadAttention(layer.StatefulLayer):
         wq, wk, wv, wo = (self._param(p) for p in ('_wq', '_wk', '_wv', '_wo'))
         bq, bk, bv, bo = (self._param(p) for p in ('_bq', '_bk', '_bv', '_bo'))
         self._query, self._key, self._value = query, key, value
-        if mask is not None and np.ndim(mask) == 0 and not mask:       # `if mask:` false (attentions.py:84,106)
+        if mask is not None and not isinstance(mask, D.AttnMask) and np.ndim(mask) == 0 and not mask:   # `if mask:` false (attentions.py:84,106)
             mask = None
-        self._mask = None if mask is None else D.AttnMask(mask, b, h, sq, skv)
+        if isinstance(mask, D.AttnMask):                               # made once by the caller (its bytes and tile summary stay
+            assert mask.dims == (b, h, sq, skv), f'AttnMask made for {mask.dims}, used with {(b, h, sq, skv)}'   # on the device)
+            self._mask = mask
+        else:
+            self._mask = None if mask is None else D.AttnMask(mask, b, h, sq, skv)
         core = D.mha_core_supported(dk, dv, any_math=self._mask is not None)
         if self._mask is not None and not core:
             raise NotImplementedError('masked attention needs head sizes Dk == Dv in {16, 32, 64, 128} (fused kernels)')

@@ -226,6 +226,54 @@ def test_mha_c4_slice(npm, exact_modes):
         assert_close(full[k], acc[k], tol=2e-5, what=k)
 
 
+@pytest.mark.parametrize('heads,causal', [(8, True), (16, False), (16, True)])
+def test_mha_c4_shape_masked_and_head_size_64(npm, heads, causal):
+    """C4's dimensions (d_model 1024, seq 512, batch 256) under a CAUSAL mask -- the tile summary at work at full size: a
+    prebuilt device mask, tiles skipped in forward and backward (mha_bwd8_kernel) -- and with 16 heads of 64 (the 8-wave
+    backward at head size 64): two samples of the full-size run against the oracle, the input gradient, and the parameter
+    gradients additive over batch halves."""
+    D = npm.device
+    rng = np.random.default_rng(heads + causal)
+    layer = npm.layers.MultiHeadAttention(num_heads=heads)
+    layer(D.from_host(np.zeros([1, 8, F], dtype=np.float32)))
+    p = {}
+    for n in O.MHA_PARAM_NAMES:
+        arr = getattr(layer, '_' + n)
+        new = (np.clip(rng.standard_normal(arr.shape), -1, 1) * (1 / np.sqrt(F) if n[0] == 'w' else 1.0)).astype(np.float32)
+        arr.set(new)
+        p[n] = new.astype(np.float64)
+    q = rng.standard_normal([B, S, F], dtype=np.float32)
+    dy = rng.standard_normal([B, S, F], dtype=np.float32) * np.float32(0.01)
+    tri = np.tril(np.ones([S, S], dtype=bool))
+    kw = lambda b: dict(mask=D.AttnMask(tri[None, None], b, heads, S, S)) if causal else {}
+    out = layer(D.from_host(q), **kw(B))
+    assert layer._core and npm._C.last_attn_kernel().startswith(f'mha_fwd_kernel D={F // heads} mask={int(causal)}')
+    rec = GradRecorder()
+    dq, dk, dv = layer(D.from_host(dy), backprop=True, optimizer_=rec)
+    assert npm._C.last_attn_kernel().startswith('mha_bwd8_kernel' if (causal or heads == 16) else 'mha_bwd16_kernel')
+    sl = slice(101, 103)
+    full_mask = np.broadcast_to(tri, (2, heads, S, S)) if causal else None
+    want, cache = O.mha_fwd(p, q[sl].astype(np.float64), mask=full_mask)
+    (wq_, wk_, wv_), _ = O.mha_bwd(p, cache, dy[sl].astype(np.float64))
+    assert_close(out.reshape(B, S * F).numpy()[sl].reshape(2, S, F), want, tol=1e-5)
+    got = sum(a.reshape(B, S * F).numpy()[sl].reshape(2, S, F).astype(np.float64) for a in (dq, dk, dv))
+    assert_close(got, wq_ + wk_ + wv_, tol=1e-5)
+    full = {k[1]: np.asarray(v) for k, v in rec.grads.items()}
+    acc = {}
+    for lo, hi in ((0, B // 2), (B // 2, B)):
+        r = GradRecorder()
+        layer(D.from_host(q[lo:hi]), **kw(hi - lo))
+        layer(D.from_host(dy[lo:hi]), backprop=True, optimizer_=r)
+        for k, v in r.grads.items():
+            acc[k[1]] = acc.get(k[1], 0) + np.asarray(v).astype(np.float64)
+    for k in full:
+        if k == '_bk':
+            bound = 1e-4 * np.abs(full['_bq']).max()
+            assert np.abs(full[k]).max() < bound and np.abs(acc[k]).max() < bound
+            continue
+        assert_close(full[k], acc[k], tol=2e-5, what=k)
+
+
 def test_dense_c1(npm, exact_modes):
     """BASELINE configs[0]: Dense(512 -> 512), batch 64 -- the whole layer against the oracle."""
     D = npm.device

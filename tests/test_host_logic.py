@@ -437,7 +437,13 @@ def test_mha_fused_core_path_on_simulator(npm, masked):
         layer(x, kv) if kv is not None else layer(x)                      # lazy init
         for n in names[:4]:       # O(1) scores: the simulator keeps the log-sum-exp in fp32, like the kernel
             getattr(layer, '_' + n).set(np.asarray(getattr(layer, '_' + n)) / np.float32(6.0))
+        if masked:                                                       # a prebuilt AttnMask is taken as is (made once, reused)
+            prebuilt = npm.device.AttnMask(mask, 2, 2, 6, skv)
+            again = layer(x, kv, mask=prebuilt) if kv is not None else layer(x, mask=prebuilt)
+            assert layer._mask is prebuilt and 'npm_mha_mask_summary' in npm._C._LIB.calls
         out = layer(x, kv, mask=mask) if kv is not None else layer(x, mask=mask)
+        if masked:
+            np.testing.assert_array_equal(np.asarray(again), np.asarray(out))
         assert layer._core and 'npm_mha_core_fwd' in npm._C._LIB.calls
         assert layer._packed is (kv is None)
         p = {n: np.asarray(getattr(layer, '_' + n)).astype(np.float64) for n in names}

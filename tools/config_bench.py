@@ -22,7 +22,8 @@ import numpy as np  # noqa: E402
 PEAK = 157.3
 MIN_SECONDS = 0.5
 NAMES = ('C2', 'C3', 'C4')
-EXTRA = ('DEC',)          # not a BASELINE.json config: TransformerDecoder at size, `--only DEC`
+EXTRA = ('DEC', 'C4M', 'C4D64')   # not BASELINE.json configs (`--only NAME`): TransformerDecoder at size; C4 under a
+#                                 causal mask (the tile summary at work); C4's dimensions with 16 heads of 64
 
 
 def timed(fn, steps, D, min_seconds=None, kernels=False):
@@ -95,6 +96,25 @@ def build_config(name, npm, D, rng, conv_batch=256):
             setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
         label = 'MultiHeadAttention d_model=1024 heads=8 seq=512 fwd+bwd+SGD, batch 256 (BASELINE.json configs[3])'
         flops = 12 * 2.0 * b * s * f * f + 6 * 2.0 * b * s * s * f
+    elif name in ('C4M', 'C4D64'):
+        b, s, f = 256, 512, 1024
+        h = 8 if name == 'C4M' else 16
+        layer = npm.layers.MultiHeadAttention(num_heads=h)
+        x = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32))
+        dy = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01))
+        mask = D.AttnMask(np.tril(np.ones([s, s], dtype=bool))[None, None], b, h, s, s) if name == 'C4M' else None   # made once
+        layer(x)
+        for n in ('_wq', '_wk', '_wv', '_wo'):
+            setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
+        label = (f'MultiHeadAttention d_model=1024 heads={h} seq=512 fwd+bwd+SGD, batch 256' +
+                 (', CAUSAL mask (reference attentions.py:105-107; TFLOP/s count the UNMASKED products: above the peak means '
+                  'skipped tiles)' if mask is not None else '') + ' (not a BASELINE.json config)')
+        flops = 12 * 2.0 * b * s * f * f + 6 * 2.0 * b * s * s * f
+
+        def step_masked():
+            layer(x, mask=mask)
+            layer(dy, backprop=True, optimizer_=sgd)
+        return label, b, flops, step_masked
     elif name == 'DEC':
         b, sq, skv, f, h, u = 64, 512, 1024, 1024, 8, 4096
         layer = npm.layers.TransformerDecoder(num_heads=h, hidden_units=u, norm_first=True)
