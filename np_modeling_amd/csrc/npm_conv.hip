@@ -29,8 +29,26 @@ struct ConvArgs {
     int korder;          // forward / grad_x K loop: 0 = taps outermost (kk = tap * C + c), 1 = 16-channel chunks outermost, the
                          // k * k taps of a chunk back to back (NPM_TUNE_CONV_KORDER)
     long slab;
+    unsigned w_mul, w_shift, h_mul, h_shift;   // n / W and n / H for 0 <= n < 2^31 as (mulhi(n, mul) >> shift), see fast_div
     Epilogue e;
 };
+
+// Division of 0 <= n < 2^31 by a run-time constant d >= 1 as one multiply-high and one shift (the compiler's own sequence
+// for `n / d` with d unknown at compile time is ~25 vector-ALU instructions, and every lane of every block divides its
+// pixel index by W and by H in the prologue -- beside three co-resident blocks of back-to-back MFMAs each of those
+// instructions costs the matrix pipe its issue cycles).  k = 31 + ceil(log2 d), mul = ceil(2^k / d) < 2^32,
+// shift = k - 32:  floor(n / d) = (n * mul) >> k exactly, because n (mul d - 2^k) < 2^31 2^ceil(log2 d) = 2^k.
+inline void fast_div_setup(unsigned d, unsigned &mul, unsigned &shift) {
+    unsigned lg = 0;
+    while ((1ull << lg) < d) ++lg;
+    const unsigned k = 31 + lg;
+    mul = (unsigned)(((1ull << k) + d - 1) / d);
+    shift = k - 32;                                   // d = 1: k = 31 -> handled below (shift would be -1)
+    if (d == 1) { mul = 0; shift = 0; }
+}
+__device__ __forceinline__ int fast_div(int n, unsigned d, unsigned mul, unsigned shift) {
+    return d == 1 ? n : (int)(__umulhi((unsigned)n, mul) >> shift);
+}
 
 // ---- forward / grad_x: A(m, kk) = X[pixel m shifted by tap(kk)][c(kk)] ----------------------
 template <bool VEC>
@@ -254,11 +272,13 @@ conv_fwd_glds_kernel(const ConvArgs p) {
         const int c = (lane & 3) ^ ((row >> 2) & 3);
         const int m = m0 + row;
         rowv[i] = m;
-        pw[i] = m % p.W;
-        ph[i] = (m / p.W) % p.H;
+        const int mrow = fast_div(m, p.W, p.w_mul, p.w_shift);           // m / W
+        pw[i] = m - mrow * p.W;
+        ph[i] = mrow - fast_div(mrow, p.H, p.h_mul, p.h_shift) * p.H;
         vbase[i] = (unsigned)((row * p.C + c * 4) * 4);
         const int mp = m0 + 16 * (A_PIECES * wave + i);         // first pixel of the piece (wave-uniform)
-        const int pwf = mp % p.W, phf = (mp / p.W) % p.H;
+        const int prow = fast_div(mp, p.W, p.w_mul, p.w_shift);
+        const int pwf = mp - prow * p.W, phf = prow - fast_div(prow, p.H, p.h_mul, p.h_shift) * p.H;
         unsigned hm = 0, wm = 0;
         if (p.ks <= 31 && pwf + 15 < p.W && mp + 15 < p.M) {
             for (int t = 0; t < p.ks; ++t) {
@@ -312,6 +332,22 @@ conv_fwd_glds_kernel(const ConvArgs p) {
 
     f32x16 acc[2][2];
     zero_acc(acc);
+    // The bias is the accumulators' INITIAL VALUE (a lane's 16 registers of an MFMA tile are one output column): the 64
+    // vector-ALU adds of the epilogue -- issued beside three co-resident blocks of back-to-back MFMAs -- are gone, for the
+    // price of the zeroing that happens anyway.  (Sums start from the bias instead of ending with it: rounding order only.)
+    Epilogue epi = p.e;
+    if (epi.flags & NPM_EPI_BIAS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l32;
+            const float bj = col < p.N ? epi.bias[col] : 0.f;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = bj;
+        }
+        epi.flags &= ~NPM_EPI_BIAS;
+    }
     f32x16 small[MATH == 2 ? 2 : 1][MATH == 2 ? 2 : 1];      // split-bf16 math, mode 2: the small terms (npm_mfma_tile.h)
     if (MATH == 2) zero_acc(reinterpret_cast<f32x16 (&)[2][2]>(small));
     const int arow = wm * 64 + l32, brow = wn * 64 + l32;
@@ -338,8 +374,8 @@ conv_fwd_glds_kernel(const ConvArgs p) {
             for (int j = 0; j < 2; ++j) acc[i][j] += reinterpret_cast<f32x16 (&)[2][2]>(small)[i][j];
     }
     prio_high(p.e.prio & 2);
-    if (p.e.buf_ok) write_tile_buf(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
-    else write_tile(acc, p.e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+    if (epi.buf_ok) write_tile_buf(acc, epi, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+    else write_tile(acc, epi, false, m0, n0, p.M, p.N, wm, wn, l32, half);
 }
 
 // grad_w: A(k = pixel, m' = (tap, c)) gathered M-major; requires C % 4 == 0, pixels % 16 == 0.
@@ -690,6 +726,8 @@ int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, in
     a.tiles_n = (a.N + BN - 1) / BN;
     a.splits = 1; a.k_per_split = a.K; a.group_m = 8;
     a.korder = g_conv_korder;
+    fast_div_setup((unsigned)w, a.w_mul, a.w_shift);
+    fast_div_setup((unsigned)h, a.h_mul, a.h_shift);
     a.e = e;
     const bool vec = c % 4 == 0 && n_out % 4 == 0 && aligned16(x) && aligned16(filt_kn);
     hipStream_t s = npm::ctx().stream;

@@ -305,6 +305,8 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
         }
         if (simple && !has_bias && alpha == 1.f) {
             NPM_STORE_ONLY(a)
+        } else if (relu && !has_bias && alpha == 1.f && !(WITH_COLSUM && want_cs)) {      // (Conv2D: the bias rode in the accumulators)
+            NPM_STORE_ONLY(fmaxf(a, 0.f))
         } else if (simple && !has_bias) {
             NPM_STORE_ONLY(alpha * a)
         } else if (simple && alpha == 1.f) {
@@ -339,6 +341,7 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
         if (key == (NPM_EPI_BIAS | NPM_EPI_RESIDUAL | 64)) rmw_epilogue<NPM_EPI_BIAS | NPM_EPI_RESIDUAL | 64, false>(acc, e, a, csum);
         else if (key == (NPM_EPI_RESIDUAL | 64) && !cs) rmw_epilogue<NPM_EPI_RESIDUAL | 64, false>(acc, e, a, csum);
         else if (key == (NPM_EPI_BIAS | NPM_EPI_RELU_SAVE | 64)) rmw_epilogue<NPM_EPI_BIAS | NPM_EPI_RELU_SAVE | 64, false>(acc, e, a, csum);
+        else if (key == (NPM_EPI_RELU_SAVE | 64) && !cs) rmw_epilogue<NPM_EPI_RELU_SAVE | 64, false>(acc, e, a, csum);
         else if (key == (NPM_EPI_RELU_MASK | 64)) { if (cs) rmw_epilogue<NPM_EPI_RELU_MASK | 64, WITH_COLSUM>(acc, e, a, csum);
                                                     else rmw_epilogue<NPM_EPI_RELU_MASK | 64, false>(acc, e, a, csum); }
         else if (key == (NPM_EPI_RELU_MASK | NPM_EPI_RESIDUAL | 64) && !cs) rmw_epilogue<NPM_EPI_RELU_MASK | NPM_EPI_RESIDUAL | 64, false>(acc, e, a, csum);
