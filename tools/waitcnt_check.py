@@ -34,6 +34,10 @@ CSRC = os.path.join(ROOT, 'np_modeling_amd', 'csrc')
 PINS = os.path.join(ROOT, 'tools', 'waitcnt_pins.json')
 HIPCC = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
 SOURCES = ('npm_attn.hip', 'npm_conv.hip', 'npm_gemm.hip')
+# The three-stage GEMM's counted wait looks at DMA pieces only (`D8 W4 B D4`: the K loop); everything behind the loop is the
+# epilogue, whose store sequences change with every epilogue specialisation and are not what the wait counts: its signature
+# ends with the loop.  The attention and convolution kernels keep theirs whole (their waits DO count trailing stores).
+LOOP_ONLY = ('npm_gemm.hip',)
 VMEM = re.compile(r'^\s*(buffer_(load|store)|global_(load|store)|scratch_(load|store)|flat_(load|store))')
 
 
@@ -66,7 +70,7 @@ def demangle(names):
     return out.stdout.split('\n')[:len(names)] if out.returncode == 0 else list(names)
 
 
-def signatures(text: str) -> dict:
+def signatures(text: str, loop_only: bool = False) -> dict:
     """{demangled kernel name: signature} for the kernels of one assembly file that contain a tagged wait."""
     found = {}
     blocks = re.split(r'\n(?=_Z\w+:\s)', text)
@@ -97,6 +101,12 @@ def signatures(text: str) -> dict:
                     push('S')
                 else:
                     push('L')
+        if loop_only:                    # up to the last tagged wait, then the barriers / DMA groups that follow it directly
+            last = max(i for i, (k, _) in enumerate(tokens) if k.startswith('W'))
+            end = last + 1
+            while end < len(tokens) and tokens[end][0] in ('B', 'D'):
+                end += 1
+            tokens = tokens[:end]
         found[head.group(1)] = ' '.join(k if n == 0 else f'{k}{n}' for k, n in tokens)
     names = list(found)
     return {d.replace('(anonymous namespace)::', ''): found[n] for n, d in zip(names, demangle(names))}
@@ -108,7 +118,7 @@ def current() -> dict:
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:          # three hipcc processes side by side
         texts = list(pool.map(assembly, SOURCES))
     for src, text in zip(SOURCES, texts):
-        for name, sig in signatures(text).items():
+        for name, sig in signatures(text, src in LOOP_ONLY).items():
             out['kernels'][f'{src}: {name}'] = sig
     return out
 
