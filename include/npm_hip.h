@@ -133,6 +133,7 @@ enum {
     NPM_TUNE_ATTN_BWD16 = 14,        /* attention backward: 2 (default) mha_bwd8_kernel (8 waves on the 16x16x4 MFMA, one barrier per tile, every head size, both score modes, tile skipping) except head size 128 with saved scores and no tile summary, which runs mha_bwd16_kernel; 3 mha_bwd8_kernel always; 1 round 3's choice (mha_bwd16_kernel for head size 128 with saved scores, the 4-wave 32x32x2 kernel otherwise); 0 the 4-wave kernel always */
     NPM_TUNE_KSYNC = 15,             /* K tiles between the soft rendezvous of the co-resident split-K blocks of the fused Conv2D filter gradient: a power of two, default 128; 0 off */
     NPM_TUNE_CONV_KORDER = 16,       /* Conv2D forward / grad_x K loop: 1 (default) the k k taps of one 16-channel chunk back to back (the lines a tap fetched are still in L2 when its neighbour wants them: grad_x of C3 reads 13.8 instead of 82 GB past the L2s, +4 %), 0 taps outermost (kk = tap C + c) */
+    NPM_TUNE_ATTN_FWD8 = 17,         /* attention forward: 2 mha_fwd8_kernel (8 waves per block on the 16x16x4 MFMA, four waves per SIMD) for every head size; 1 below head size 128 only; 0 the 4-wave 32x32x2 mha_fwd_kernel always */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
     NPM_TUNE_GEMM_ABLATE = 99
 };

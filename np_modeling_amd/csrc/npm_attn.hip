@@ -459,6 +459,292 @@ mha_fwd_kernel(const MhaArgs p) {
   }   // rep
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
+
+// ---------------------------------------------------------------------------------------------------------------
+// Forward on v_mfma_f32_16x16x4_f32, EIGHT wavefronts per block (round 4).  The 32 x 32 kernel above gives a wave 32
+// queries; its O^T accumulators have the HEAD DIMENSION on the rows of 32 x 32 tiles, so head size 16 multiplies half of
+// its P V tiles by padding, and at 200+ registers only two waves share a SIMD.  Here a wave owns 16 queries of the block's
+// 128: the Q fragment (D / 4 registers), the O^T accumulators (D / 4) and two 16 x 16 score tiles fit 128 registers, FOUR
+// waves share a SIMD (two blocks of eight per CU), and every head size fills its tiles.
+//   S^T[kv, q] = K Q^T   A = row kv = 16 t + l16 of the K tile, 16 bytes at d = 16 c + 4 kk (one LDS read per 4 MFMAs),
+//                        B = the Q fragment; the result has its query on the lane (column l16) and keys 16 t + 4 kk + r in
+//                        registers: the softmax statistics of a query live on its four lanes (two cross-lane steps each),
+//   O^T[d, q] += V^T[d, kv] P^T[kv, q]   B = P[t][r], register for register the result of the exp; A = VW = min(4, D / 16)
+//                        adjacent head dimensions of V row kv = 16 t + 4 kk + r (element e belongs to d-tile e).
+// Same K / V tiles of 32 keys through two LDS stages, same online softmax, masks, saved scores, tile skipping and pairing
+// as mha_fwd_kernel.
+// ---------------------------------------------------------------------------------------------------------------
+template <int D, bool MASK, bool SAVE>
+__global__ void __launch_bounds__(512, 4)
+mha_fwd8_kernel(const MhaArgs p) {
+    using T = Tile<D>;
+    constexpr int NC = D / 16, TILE = 32 * D, ROWS16 = 16 * D;
+    constexpr int PIECES = D / 8, PPW = PIECES >= 8 ? PIECES / 8 : 1;             // 1 KiB DMA pieces of a K (or V) tile; per wave
+    constexpr int VW = D >= 64 ? 4 : D / 16, NV = NC / VW, NB = NC < 4 ? NC : 4;
+    __shared__ __attribute__((aligned(16))) float smem[4 * TILE];                // K stages 0 / 1, V stages 0 / 1
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                  // 0 .. 7
+    const int l16 = lane & 15, kk = lane >> 4;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const bool pairing = MASK && p.q_pair;                                       // see mha_fwd_kernel
+    const int units = pairing ? (p.q_tiles + 1) / 2 : p.q_tiles;
+    const int unit = logical % units, bh = logical / units;
+    const int b = bh / p.heads, h = bh - b * p.heads;
+    const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
+    const auto descV = make_desc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
+    const auto rsrcQ = make_rsrc(p.q + (long)b * p.seq_q * p.q_pitch + h * D, ((long)(p.seq_q - 1) * p.q_pitch + D) * 4);
+    const auto rsrcC = make_rsrc(p.ctx + (long)b * p.seq_q * p.ctx_pitch + h * D, ((long)(p.seq_q - 1) * p.ctx_pitch + D) * 4);
+    const auto rsrcM = make_rsrc(MASK ? p.mask + b * p.mask_sb + h * p.mask_sh : nullptr, MASK ? (long)(p.seq_q - 1) * p.mask_sq + p.seq_kv : 0);
+    const auto rsrcS = make_rsrc(SAVE ? p.scores + (long)bh * p.seq_q * p.seq_kv : nullptr, SAVE ? (long)p.seq_q * p.seq_kv * 4 : 0);
+    const bool mask_dw = MASK && (p.mask_sq & 3) == 0 && (p.seq_kv & 3) == 0 && ((unsigned long)(p.mask + b * p.mask_sb + h * p.mask_sh) & 3) == 0;
+    const bool rows16 = (p.seq_kv & 3) == 0;                                     // every score row starts 16-byte aligned
+    const float c = p.scale * LOG2E;
+    const int nt = (p.seq_kv + 31) / 32;
+
+    unsigned vk[PPW], vv[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        vk[i] = T::src(lane, wave * PPW + i, p.k_pitch);
+        vv[i] = T::src(lane, wave * PPW + i, p.v_pitch);
+    }
+    const bool owner = PIECES >= 8 || wave < PIECES;                             // D < 64: fewer pieces than waves
+    const unsigned kstep = (unsigned)(32 * p.k_pitch * 4), vstep = (unsigned)(32 * p.v_pitch * 4);
+    const unsigned lds_k = lds_offset(smem + wave * PPW * 256), lds_v = lds_k + 2 * TILE * 4;
+    auto issue = [&](int t, int stage) {
+        if (owner) {
+            const unsigned tu = (unsigned)__builtin_amdgcn_readfirstlane(t);
+            dma_group<PPW>(descK, lds_k + stage * TILE * 4, tu * kstep, vk);
+            dma_group<PPW>(descV, lds_v + stage * TILE * 4, tu * vstep, vv);
+        }
+    };
+    int rb[NB], vb[4];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) rb[j] = T::chunk(l16, 4 * j + kk);             // K rows 16 t + l16, chunk 4 c + kk: + t ROWS16 + (c >> 2) 64
+#pragma unroll
+    for (int j = 0; j < 4; ++j) vb[j] = T::elem(4 * kk + j, VW * l16);          // V rows 16 t + 4 kk + r, columns VW l16 ..: + t ROWS16 (+ 64)
+
+  for (int rep = 0; rep < (pairing ? 2 : 1); ++rep) {
+    const int qt = rep == 0 ? unit : p.q_tiles - 1 - unit;
+    if (rep == 1) {
+        if (qt == unit) break;
+        __syncthreads();
+    }
+    const int qrow = qt * 128 + wave * 16 + l16;                                 // this lane's query (shared by its four lanes kk)
+    const bool qok = qrow < p.seq_q;
+    const int mvoff = qok ? (int)(qrow * p.mask_sq + 4 * kk) : OOB;              // mask bytes: this query's row, keys 4 kk ..
+    const int svoff = qok ? (int)(((long)qrow * p.seq_kv + 4 * kk) * 4) : OOB;   // saved scores, the same way
+
+    // tiles this block / this wave visits, tiles without an excluded position (see mha_fwd_kernel)
+    unsigned long act = ~0ul, mine = ~0ul, plain = 0ul;
+    const bool skipping = MASK && p.skip != nullptr;
+    if (skipping) {
+        const unsigned char *sk = p.skip + b * p.skip_sb + h * p.skip_sh;
+        unsigned any = 0, own = 0, full = 0;
+        const int mytile = 4 * qt + (wave >> 1);                                 // the summary row (32 queries) of this wave's 16
+        if (lane < nt) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int qtile = 4 * qt + i;
+                const unsigned bits = qtile * 32 < p.seq_q ? (sk[(long)qtile * p.skip_nkb + (lane >> 2)] >> (2 * (lane & 3))) & 3u : 0u;
+                any |= bits;
+                if (qtile == mytile) own = bits;
+            }
+            if (p.skip_all && mytile * 32 < p.seq_q)
+                full = (sk[p.skip_all + (long)mytile * p.skip_nkb + (lane >> 2)] >> (2 * (lane & 3))) & 3u;
+        }
+        act = __builtin_amdgcn_ballot_w64(any != 0);
+        mine = __builtin_amdgcn_ballot_w64(own != 0);
+        plain = __builtin_amdgcn_ballot_w64(full == 3u);
+    }
+    const int t_first = skipping ? (act ? __builtin_ctzl(act) : -1) : 0;
+    if (t_first >= 0) issue(t_first, 0);
+    float4 qf[NC];                                                               // Q[qrow][16 c + 4 kk + s] (loaded behind the summary's
+#pragma unroll                                                                   //  temporaries: the register file is full at D = 128)
+    for (int cc = 0; cc < NC; ++cc) qf[cc] = buf_load4(rsrcQ, qok ? (int)((qrow * p.q_pitch + 16 * cc + 4 * kk) * 4) : OOB);
+
+    f32x4 O[NC];
+#pragma unroll
+    for (int x = 0; x < NC; ++x) O[x] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+
+    auto tile = [&](auto stage_c, const int t, const int t_next) __attribute__((always_inline)) {
+        constexpr int STG = decltype(stage_c)::value;
+        npm_tile::dma_barrier();                        // tile t has landed (every wave's pieces); nobody still reads the stage refilled next
+        if (t_next >= 0) issue(t_next, STG ^ 1);
+        if (skipping && !((mine >> t) & 1)) return;
+        const float *sK = smem + STG * TILE, *sV = smem + (2 + STG) * TILE;
+        const bool masked_tile = MASK && !((plain >> t) & 1);
+        unsigned mkw[2];                                // the 4 keys of a register group are 4 adjacent mask bytes
+        if (masked_tile && mask_dw) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) mkw[g2] = __builtin_amdgcn_raw_buffer_load_b32(rsrcM, mvoff + 16 * g2, 32 * t, 0);
+        }
+        // ---- S^T[kv, q] = K Q^T: NC steps of (2 row reads, 8 MFMAs), reads one step ahead
+        f32x4 S[2];
+        constexpr int AHEAD = (MASK && D == 128) ? 0 : 1;   // K rows one step ahead -- not in the instances at the register limit
+        float4 fk[2][2];
+        if (AHEAD) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) fk[0][g2] = ld4(sK + rb[0] + g2 * ROWS16);
+        }
+#pragma unroll
+        for (int cc = 0; cc < NC; ++cc) {
+            if (AHEAD && cc + 1 < NC) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) fk[(cc + 1) & 1][g2] = ld4(sK + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + g2 * ROWS16);
+            }
+            if (!AHEAD) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) fk[cc & 1][g2] = ld4(sK + rb[cc & 3] + (cc >> 2) * 64 + g2 * ROWS16);
+            }
+            FENCE();
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2) {
+                if (cc == 0) {                          // the first MFMA starts from the constant 0: nothing zeroes S
+                    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+                    S[g2] = MFMA16(fk[0][g2].x, qf[0].x, zero);
+                } else {
+                    S[g2] = MFMA16(fk[cc & 1][g2].x, qf[cc].x, S[g2]);
+                }
+                S[g2] = MFMA16(fk[cc & 1][g2].y, qf[cc].y, S[g2]);
+                S[g2] = MFMA16(fk[cc & 1][g2].z, qf[cc].z, S[g2]);
+                S[g2] = MFMA16(fk[cc & 1][g2].w, qf[cc].w, S[g2]);
+            }
+            FENCE();
+        }
+        // first vectors of the P V product: requested under the softmax -- except in the masked instances at D = 128, which
+        // sit at the 128-register limit of four waves per SIMD (they spilled 6-8 registers): there behind it
+        constexpr bool EARLY_V = !(MASK && D == 128);
+        float ev[2][NV][4];
+        if (EARLY_V) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ldv<VW>(sV + vb[0] + 64 * v, ev[0][v]);
+        }
+        const int kv0 = 32 * t + 4 * kk;                // register r of group g2 holds key kv0 + 16 g2 + r
+        if (32 * t + 32 > p.seq_kv) {
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (kv0 + 16 * g2 + r >= p.seq_kv) S[g2][r] = -INFINITY;
+        }
+        if (masked_tile) {
+            if (!mask_dw) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    mkw[g2] = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        mkw[g2] |= (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff + e + 16 * g2, 32 * t, 0) << (8 * e);
+                }
+            }
+#pragma unroll
+            for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    if (((mkw[g2] >> (8 * r)) & 0xffu) == 0) S[g2][r] = -INFINITY;
+        }
+        if (SAVE) {
+            const int stile = 32 * t * 4;
+            if (rows16 && 32 * t + 32 <= p.seq_kv) {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2) {
+                    const u32x4_t v = {__float_as_uint(S[g2][0]), __float_as_uint(S[g2][1]), __float_as_uint(S[g2][2]), __float_as_uint(S[g2][3])};
+                    __builtin_amdgcn_raw_buffer_store_b128(v, rsrcS, svoff + 64 * g2, stile, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(S[g2][r]), rsrcS,
+                                                              (qok && kv0 + 16 * g2 + r < p.seq_kv) ? svoff + 64 * g2 + 4 * r : OOB, stile, 0);
+            }
+        }
+        // ---- online softmax in the exp2 domain (mha_fwd_kernel's rules: lazy reference point, rows that start masked)
+        constexpr float RESCALE = 10.f;
+        float tmax = fmaxf(fmaxf(fmaxf(S[0][0], S[0][1]), fmaxf(S[0][2], S[0][3])), fmaxf(fmaxf(S[1][0], S[1][1]), fmaxf(S[1][2], S[1][3])));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
+        float m_new = m;
+        if (__builtin_amdgcn_ballot_w64(tmax > m + RESCALE) != 0) {
+            m_new = fmaxf(m, tmax);
+            const float alpha = (MASK && m == -INFINITY) ? 0.f : fast_exp2(m - m_new);
+            l *= alpha;
+#pragma unroll
+            for (int x = 0; x < NC; ++x)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) O[x][e] *= alpha;
+        }
+        const float m_use = (MASK && m_new == -INFINITY) ? 0.f : m_new;
+        float psum = 0.f;
+#pragma unroll
+        for (int g2 = 0; g2 < 2; ++g2)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                S[g2][r] = fast_exp2(fmaf(S[g2][r], c, -m_use));
+                psum += S[g2][r];
+            }
+        psum += __shfl_xor(psum, 16, 64);
+        psum += __shfl_xor(psum, 32, 64);
+        l += psum;
+        m = m_new;
+        FENCE();
+        // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]: 8 steps (one key row per lane quarter each) of (NV vector reads, NC MFMAs)
+        if (!EARLY_V) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) ldv<VW>(sV + vb[0] + 64 * v, ev[0][v]);
+        }
+#pragma unroll
+        for (int st = 0; st < 8; ++st) {
+            const int g2 = st >> 2, r = st & 3;
+            if (st + 1 < 8) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) ldv<VW>(sV + vb[(st + 1) & 3] + ((st + 1) >> 2) * ROWS16 + 64 * v, ev[(st + 1) & 1][v]);
+            }
+            FENCE();
+#pragma unroll
+            for (int x = 0; x < NC; ++x) O[x] = MFMA16(ev[st & 1][x / VW][x % VW], S[g2][r], O[x]);
+            FENCE();
+        }
+    };
+    auto next_tile = [&](int t) -> int {
+        if (!skipping) return t + 1 < nt ? t + 1 : -1;
+        const unsigned long mm = t < 63 ? act >> (t + 1) : 0ul;
+        return mm ? t + 1 + __builtin_ctzl(mm) : -1;
+    };
+    for (int t = t_first; t >= 0;) {
+        const int t1 = next_tile(t);
+        tile(std::integral_constant<int, 0>{}, t, t1);
+        if (t1 < 0) break;
+        const int t2 = next_tile(t1);
+        tile(std::integral_constant<int, 1>{}, t1, t2);
+        t = t2;
+    }
+
+    const float inv = 1.f / l;
+    if (kk == 0 && qok) p.lse[(long)bh * p.seq_q + qrow] = (m + __builtin_amdgcn_logf(l)) * LN2;       // v_log_f32 is log2
+    // register r of the d-tiles of one vector read together: VW adjacent head dimensions from VW (4 kk + r); r = 0 .. 3 continue them
+#pragma unroll
+    for (int x4 = 0; x4 < (NC + 3) / 4; ++x4)
+#pragma unroll
+        for (int r0 = 0; r0 < 4; r0 += 4 / VW) {
+            const int d0 = 64 * x4 + VW * (4 * kk + r0);
+            const int off = qok ? (int)((qrow * p.ctx_pitch + d0) * 4) : OOB;
+            float o4[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = 4 * x4 + e % VW, r = r0 + e / VW;
+                o4[e] = O[x < NC ? x : 0][r & 3] * inv;
+            }
+            buf_store4(rsrcC, off, o4[0], o4[1], o4[2], o4[3]);
+        }
+  }   // rep
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Backward.  One block = 4 wavefronts = one (batch, head); one block per CU (145 KB of LDS at D = 128, the whole
 // register file per wave).  Outer loop: key blocks of 128 (wave w owns keys 32 w .. 32 w + 31 of the block, its dK^T
@@ -834,8 +1120,6 @@ mha_bwd_kernel(const MhaArgs p) {
 //                                        A = K[kv = 16 c + 4 kk + s][d] (4-byte reads of the K block), B = row q of the dS
 //                                        tile in LDS, 16 bytes at kv = 16 c + 4 kk
 // ---------------------------------------------------------------------------------------------------------------
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-#define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 __global__ void __launch_bounds__(512, 1)
 mha_bwd16_kernel(const MhaArgs p) {
@@ -1547,6 +1831,8 @@ mha_bwd8_kernel(const MhaArgs p) {
 long long *g_attn_trace = nullptr;
 int g_attn_stagger = 1;
 int g_attn_pair = 1;           // forward with a tile summary: two query tiles per block (see mha_fwd_kernel); NPM_TUNE_ATTN_STAGGER's bit 8 clears it
+int g_attn_fwd8 = 2;           // NPM_TUNE_ATTN_FWD8: 2 mha_fwd8_kernel (8 waves, 16x16x4 MFMA) for every head size, 1 below head size 128 only,
+                               // 0 the 4-wave 32x32x2 mha_fwd_kernel always
 int g_attn_bwd16 = 2;          // NPM_TUNE_ATTN_BWD16: 2 (default) mha_bwd8_kernel, except head size 128 with saved scores and no tile
                                // summary, which stays on mha_bwd16_kernel (4.59 against 4.86 ms at C4: fewer vector-ALU instructions per
                                // tile); 3 mha_bwd8_kernel for everything; 1 round 3's choice (mha_bwd16_kernel for head size 128 with
@@ -1663,6 +1949,15 @@ template <int D>
 int launch_fwd(const MhaArgs &a, hipStream_t s) {
     const int grid = a.batch * a.heads * (a.q_pair ? (a.q_tiles + 1) / 2 : a.q_tiles);
     const bool mask = a.mask != nullptr, save = a.scores != nullptr;
+    if ((g_attn_fwd8 == 2 || (g_attn_fwd8 == 1 && D < 128)) && !a.trace) {
+        if (mask && save) hipLaunchKernelGGL((mha_fwd8_kernel<D, true, true>), dim3(grid), dim3(512), 0, s, a);
+        else if (mask) hipLaunchKernelGGL((mha_fwd8_kernel<D, true, false>), dim3(grid), dim3(512), 0, s, a);
+        else if (save) hipLaunchKernelGGL((mha_fwd8_kernel<D, false, true>), dim3(grid), dim3(512), 0, s, a);
+        else hipLaunchKernelGGL((mha_fwd8_kernel<D, false, false>), dim3(grid), dim3(512), 0, s, a);
+        note_kernel("mha_fwd8_kernel", D, mask, save);
+        NPM_CHECK_LAUNCH();
+        return NPM_OK;
+    }
     if (mask && save) launch_fwd_instance<D, true, true>(a, grid, s);
     else if (mask) launch_fwd_instance<D, true, false>(a, grid, s);
     else if (save) launch_fwd_instance<D, false, true>(a, grid, s);
@@ -1767,6 +2062,7 @@ extern "C" int npm_attn_set_stagger(int units) {
     g_attn_stagger = units < 0 ? 0 : (units & 255);
     return NPM_OK;
 }
+extern "C" int npm_attn_set_fwd8(int mode) { g_attn_fwd8 = mode < 0 ? 0 : mode > 2 ? 2 : mode; return NPM_OK; }
 extern "C" int npm_attn_set_bwd16(int on) { g_attn_bwd16 = on < 0 ? 0 : on > 3 ? 3 : on; return NPM_OK; }
 
 extern "C" const char *npm_last_attn_kernel(void) { return g_attn_last; }

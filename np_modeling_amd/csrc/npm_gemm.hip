@@ -433,6 +433,7 @@ extern "C" int npm_conv_set_korder(int order);
 extern "C" int npm_conv_set_math(int mode);
 extern "C" int npm_conv_set_wgrad_fused(int mode);
 extern "C" int npm_attn_set_bwd16(int on);
+extern "C" int npm_attn_set_fwd8(int mode);
 extern "C" int npm_attn_set_stagger(int units);
 
 extern "C" int npm_set_math(int mode) { return npm_set_tuning(NPM_TUNE_GEMM_MATH, mode); }
@@ -458,6 +459,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         case NPM_TUNE_ATTN_STAGGER: return npm_attn_set_stagger(value);
         case NPM_TUNE_ATTN_BWD16: return npm_attn_set_bwd16(value);
+        case NPM_TUNE_ATTN_FWD8: return npm_attn_set_fwd8(value);
         case NPM_TUNE_KSYNC: npm::set_ksync_every(value); return NPM_OK;
         case NPM_TUNE_CONV_KORDER: return npm_conv_set_korder(value);
         case NPM_TUNE_STREAM_NT: npm::set_stream_nt(value); return NPM_OK;

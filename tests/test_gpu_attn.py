@@ -41,6 +41,16 @@ def bwd_kernel(request, npm):
     _C.check(_C.lib().npm_set_tuning(14, 2), 'npm_set_tuning')
 
 
+@pytest.fixture(params=[2, 0], ids=['fwd8', 'fwd4'], autouse=True)
+def fwd_kernel(request, npm):
+    """... and under each attention forward (NPM_TUNE_ATTN_FWD8): 2 = mha_fwd8_kernel (8 waves on the 16x16x4 MFMA), 0 = the 4-wave
+    32x32x2 mha_fwd_kernel."""
+    from np_modeling_amd import _C
+    _C.check(_C.lib().npm_set_tuning(17, request.param), 'npm_set_tuning')
+    yield request.param
+    _C.check(_C.lib().npm_set_tuning(17, 2), 'npm_set_tuning')
+
+
 def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=False, lse_ctx=None, skip=True):
     """q [B,Sq,H,D], k/v [B,Skv,H,D] host arrays -> dict of host results from the C ABI.  ``packed``: q, k, v
     live in one [B, S, 3, H, D] buffer (row pitch 3 H D), like the layer's packed projection."""

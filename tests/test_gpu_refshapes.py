@@ -22,6 +22,7 @@ def npm():
 
 
 ATTENTION = [n for n, c in R.CASES.items() if c['kind'] in ('mha', 'encoder', 'decoder')]
+FWD = 'mha_fwd8_kernel'            # the default forward (NPM_TUNE_ATTN_FWD8 = 2); the 4-wave mha_fwd_kernel: test_reference_outputs_other_forward
 
 
 @pytest.mark.parametrize('name', ATTENTION)
@@ -34,7 +35,7 @@ def test_reference_outputs(npm, name, math_mode):
         for att in RR.attention_layers(layer, case):
             assert att._core is fused
         if fused:
-            assert npm._C.last_attn_kernel().startswith(f'mha_fwd_kernel D={d} mask=0 scores=1'), npm._C.last_attn_kernel()
+            assert npm._C.last_attn_kernel() == f'{FWD} D={d} mask=0 scores=1', npm._C.last_attn_kernel()
             assert npm.last_math() == 'f32'
 
     def after_backward(layer):
@@ -62,6 +63,19 @@ def test_reference_outputs_other_backward_kernels(npm, name, knob):
     RR.compare(got, ref, tol=1e-5)
 
 
+@pytest.mark.parametrize('name', [n for n in ATTENTION if R.CASES[n]['kind'] == 'mha'])
+def test_reference_outputs_other_forward(npm, name):
+    """The 4-wave 32x32x2 forward (NPM_TUNE_ATTN_FWD8 = 0) stays selectable and runs the same fixtures."""
+    from np_modeling_amd import _C
+    d = R.CASES[name]['feat'] // R.CASES[name]['heads']
+    _C.check(_C.lib().npm_set_tuning(17, 0), 'npm_set_tuning')
+    try:
+        got, ref = RR.run(npm, name, after_forward=lambda layer: _assert_kernel(npm, f'mha_fwd_kernel D={d} mask=0 scores=1'))
+    finally:
+        _C.check(_C.lib().npm_set_tuning(17, 2), 'npm_set_tuning')
+    RR.compare(got, ref, tol=1e-5)
+
+
 def _assert_kernel(npm, want):
     assert npm._C.last_attn_kernel() == want, npm._C.last_attn_kernel()
 
@@ -77,7 +91,7 @@ def test_reference_outputs_recomputing_backward(npm, name):
     try:
         def after_forward(layer):
             assert layer._core and layer._raw_scores is None
-            assert npm._C.last_attn_kernel() == f'mha_fwd_kernel D={d} mask=0 scores=0'
+            assert npm._C.last_attn_kernel() == f'{FWD} D={d} mask=0 scores=0'
 
         def after_backward(layer):
             assert npm._C.last_attn_kernel() == f'mha_bwd8_kernel D={d} mask=0 scores=0'

@@ -22,6 +22,7 @@ then `python tools/waitcnt_check.py --pin`.
 """
 
 import argparse
+import functools
 import json
 import os
 import re
@@ -48,6 +49,7 @@ def compiler_version() -> str:
     return f'hip {hip.group(1) if hip else "?"} clang {clang.group(1) if clang else "?"}'
 
 
+@functools.lru_cache(maxsize=None)
 def assembly(source: str) -> str:
     with tempfile.TemporaryDirectory() as tmp:
         out = os.path.join(tmp, 'a.s')
@@ -108,6 +110,28 @@ def signatures(text: str, loop_only: bool = False) -> dict:
                 end += 1
             tokens = tokens[:end]
         found[head.group(1)] = ' '.join(k if n == 0 else f'{k}{n}' for k, n in tokens)
+    names = list(found)
+    return {d.replace('(anonymous namespace)::', ''): found[n] for n, d in zip(names, demangle(names))}
+
+
+def scratch_depth(text: str) -> dict:
+    """{demangled kernel name: deepest loop nesting at which a scratch (spill) instruction sits} for the kernels of one
+    assembly file that touch scratch at all; 0 = straight-line code.  The compiler annotates every block of a loop with
+    `in Loop: Header=... Depth=N` (`Inner Loop Header: Depth=N` / `Loop Header: Depth=N` on the header itself)."""
+    found = {}
+    for block in re.split(r'\n(?=_Z\w+:\s)', text):
+        head = re.match(r'(_Z\w+):', block)
+        if not head:
+            continue
+        depth, worst = 0, None
+        for line in block.split('.Lfunc_end', 1)[0].splitlines():
+            if re.match(r'\.LBB\w+:', line):
+                d = re.search(r'Depth=(\d+)', line)
+                depth = int(d.group(1)) if d else 0
+            elif re.match(r'\s*scratch_(load|store)', line):
+                worst = depth if worst is None else max(worst, depth)
+        if worst is not None:
+            found[head.group(1)] = worst
     names = list(found)
     return {d.replace('(anonymous namespace)::', ''): found[n] for n, d in zip(names, demangle(names))}
 
