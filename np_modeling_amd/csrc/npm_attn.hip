@@ -460,6 +460,18 @@ mha_fwd_kernel(const MhaArgs p) {
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// maxima as the instructions are: fmaxf() canonicalises each input first (a v_max_f32 x, x per operand)
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+__device__ __forceinline__ float fmax_raw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -665,10 +677,13 @@ mha_fwd8_kernel(const MhaArgs p) {
             }
         }
         // ---- online softmax in the exp2 domain (mha_fwd_kernel's rules: lazy reference point, rows that start masked)
+        // (vector-ALU diet: four waves share a SIMD here and every vector instruction takes issue cycles from the other
+        //  three's MFMAs -- three-input maxima without the canonicalising self-maxima fmaxf brings, packed fma / add)
         constexpr float RESCALE = 10.f;
-        float tmax = fmaxf(fmaxf(fmaxf(S[0][0], S[0][1]), fmaxf(S[0][2], S[0][3])), fmaxf(fmaxf(S[1][0], S[1][1]), fmaxf(S[1][2], S[1][3])));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64)) * c;
+        float tmax = max3(max3(max3(S[0][0], S[0][1], S[0][2]), S[0][3], S[1][0]), S[1][1], S[1][2]);
+        tmax = fmax_raw(tmax, S[1][3]);
+        tmax = fmax_raw(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmax_raw(tmax, __shfl_xor(tmax, 32, 64)) * c;
         float m_new = m;
         if (__builtin_amdgcn_ballot_w64(tmax > m + RESCALE) != 0) {
             m_new = fmaxf(m, tmax);
@@ -680,14 +695,19 @@ mha_fwd8_kernel(const MhaArgs p) {
                 for (int e = 0; e < 4; ++e) O[x][e] *= alpha;
         }
         const float m_use = (MASK && m_new == -INFINITY) ? 0.f : m_new;
-        float psum = 0.f;
+        const f32x2 c2 = {c, c}, m2 = {-m_use, -m_use};
+        f32x2 ps = {0.f, 0.f};
 #pragma unroll
         for (int g2 = 0; g2 < 2; ++g2)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                S[g2][r] = fast_exp2(fmaf(S[g2][r], c, -m_use));
-                psum += S[g2][r];
+            for (int r = 0; r < 4; r += 2) {
+                const f32x2 a = __builtin_elementwise_fma(f32x2{S[g2][r], S[g2][r + 1]}, c2, m2);
+                const f32x2 e = {fast_exp2(a.x), fast_exp2(a.y)};
+                S[g2][r] = e.x;
+                S[g2][r + 1] = e.y;
+                ps += e;
             }
+        float psum = ps.x + ps.y;
         psum += __shfl_xor(psum, 16, 64);
         psum += __shfl_xor(psum, 32, 64);
         l += psum;
@@ -1232,6 +1252,8 @@ mha_bwd16_kernel(const MhaArgs p) {
             for (int t = 0; t < 2; ++t) { Lr[t] = Lr_n[t]; Dr[t] = Dr_n[t]; }
             load_rows(32 * nq);
             // raw scores of this tile (nontemporal: read once) and the old dQ values (the dQ accumulators start from them)
+            // (requesting the scores a whole tile ahead, like the row terms, was measured in round 4: 4.56 -> 4.58-4.62 ms --
+            //  their trip from HBM is covered by the dP product)
             f32x4 S[2], acc[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t)

@@ -427,10 +427,22 @@ FUSE_SOFTMAX_BWD = os.environ.get('NPM_FUSE_SOFTMAX_BWD', '1') != '0'
 FUSE_BSUM = os.environ.get('NPM_FUSE_BSUM', '1') != '0'          # bias gradient inside the weight-gradient GEMM
 PACK_QKV = os.environ.get('NPM_PACK_QKV', '1') != '0'
 ATTN_CORE = os.environ.get('NPM_ATTN_CORE', '1') != '0'            # fused attention core (npm_mha_core_*) where it applies
-# The forward keeps the raw scores for the backward by default: on this chip the fp32 matrix rate is the scarce
-# resource (a 32 x 32 score tile costs 64 MFMAs to recompute, 16 loads to read back; measured 5.25 vs 5.86 ms for the
-# C4 backward); NPM_ATTN_SAVE_SCORES=0 is the memory-lean mode (log-sum-exp only, 2.1 GB less at C4 / C5).
-ATTN_SAVE_SCORES = os.environ.get('NPM_ATTN_SAVE_SCORES', '1') != '0'
+# Whether the forward keeps the raw scores for the backward.  The fp32 matrix rate is the scarce resource at the large
+# head sizes (a 32 x 32 score tile costs 64 MFMAs to recompute at D = 128, 16 loads to read back: forward + backward of the C4
+# core 6.6 ms with saved scores against 7.5 ms recomputing); the score tensor does not shrink with the head size while the
+# matrix work does, so at small head sizes writing and reading it is what the kernels wait for (H D = 1024, B 256, S 512,
+# forward + backward: D 64 7.6 saved / 7.9 ms recomputed, D 32 8.8 / 8.7, D 16 13.4 / 10.4: profiles/r04_attn_modes.log).
+# Default: keep them from head size 64 up.  NPM_ATTN_SAVE_SCORES=1 / 0 forces either mode everywhere (0 is the memory-lean
+# mode: log-sum-exp only, 2.1 GB less at C4 / C5).
+_save = os.environ.get('NPM_ATTN_SAVE_SCORES', '')
+ATTN_SAVE_SCORES: Optional[bool] = None if _save == '' else _save != '0'
+ATTN_SAVE_SCORES_FROM = 64
+
+
+def attn_save_scores(head_size: int) -> bool:
+    return head_size >= ATTN_SAVE_SCORES_FROM if ATTN_SAVE_SCORES is None else bool(ATTN_SAVE_SCORES)
+
+
 # masked attention: let the fused kernels skip tiles without an allowed position (NPM_ATTN_TILE_SKIP=0: visit them all)
 ATTN_TILE_SKIP = os.environ.get('NPM_ATTN_TILE_SKIP', '1') != '0'
 

@@ -162,7 +162,7 @@ class MultiHeadAttention(layer.StatefulLayer):
             # scores, softmax and context in one kernel; what the backward needs is the log-sum-exp per row
             ctx, self._lse, self._raw_scores = D.mha_core_fwd(
                 Mat(q, pq), Mat(k, pk), Mat(v, pv), (b, h, sq, skv, dk), self._scale, self._mask,
-                save_scores=D.ATTN_SAVE_SCORES)
+                save_scores=D.attn_save_scores(dk))
             self._softmax._y = self._attention_scores = None
         else:
             # attention[b, h] = q_h k_h^T ; scores = softmax(attention / sqrt(dk))

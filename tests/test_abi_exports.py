@@ -130,11 +130,11 @@ def test_no_kernel_spills_vector_registers(built):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import kernel_meta
     lib_dir = os.path.dirname(built.LIB_PATH)
-    # The masked, score-saving forward at head size 128 sits at the 128-register budget of eight waves per block; the
-    # compiler parks six values of the tile-summary setup in scratch.  That is accepted ONLY while every scratch access
-    # stays outside the key-tile loop (nesting depth 2: blocks of the query-tile pair loop at depth 1 run once or twice
-    # per block) -- checked on the disassembly below.
-    OUTSIDE_THE_TILE_LOOP = ('mha_fwd8_kernel<128, true, true>',)
+    # The masked forward at head size 128 sits at the 128-register budget of eight waves per block; the compiler parks
+    # four to six values of the tile-summary setup in scratch.  That is accepted ONLY while every scratch access stays
+    # outside the key-tile loop (nesting depth 2: blocks of the query-tile pair loop at depth 1 run once or twice per
+    # block) -- checked on the disassembly below.
+    OUTSIDE_THE_TILE_LOOP = ('mha_fwd8_kernel<128, true, true>', 'mha_fwd8_kernel<128, true, false>')
     seen, spilled = 0, []
     for obj in sorted(glob.glob(os.path.join(lib_dir, 'npm_*.o'))):
         for name, meta in kernel_meta.kernel_metadata(obj).items():

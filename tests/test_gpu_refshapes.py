@@ -35,13 +35,13 @@ def test_reference_outputs(npm, name, math_mode):
         for att in RR.attention_layers(layer, case):
             assert att._core is fused
         if fused:
-            assert npm._C.last_attn_kernel() == f'{FWD} D={d} mask=0 scores=1', npm._C.last_attn_kernel()
+            assert npm._C.last_attn_kernel() == f'{FWD} D={d} mask=0 scores={int(d >= 64)}', npm._C.last_attn_kernel()
             assert npm.last_math() == 'f32'
 
     def after_backward(layer):
         if fused:
             last = npm._C.last_attn_kernel()
-            assert last == f'{"mha_bwd16_kernel" if d == 128 else "mha_bwd8_kernel"} D={d} mask=0 scores=1', last
+            assert last == f'{"mha_bwd16_kernel" if d == 128 else "mha_bwd8_kernel"} D={d} mask=0 scores={int(d >= 64)}', last
 
     got, ref = RR.run(npm, name, after_forward, after_backward)
     RR.compare(got, ref, tol=1e-5)
@@ -54,11 +54,15 @@ def test_reference_outputs_other_backward_kernels(npm, name, knob):
     1 = mha_bwd16_kernel (head size 128) / the 4-wave mha_bwd_kernel, 0 = the 4-wave kernel."""
     from np_modeling_amd import _C
     d = R.CASES[name]['feat'] // R.CASES[name]['heads']
+    from np_modeling_amd import device as D
     want = 'mha_bwd8_kernel' if knob == 3 else ('mha_bwd16_kernel' if (knob == 1 and d == 128) else 'mha_bwd_kernel')
     _C.check(_C.lib().npm_set_tuning(14, knob), 'npm_set_tuning')
+    saved = D.ATTN_SAVE_SCORES
+    D.ATTN_SAVE_SCORES = True                      # every head size with saved scores (the default keeps them from 64 up)
     try:
         got, ref = RR.run(npm, name, after_backward=lambda layer: _assert_kernel(npm, f'{want} D={d} mask=0 scores=1'))
     finally:
+        D.ATTN_SAVE_SCORES = saved
         _C.check(_C.lib().npm_set_tuning(14, 2), 'npm_set_tuning')
     RR.compare(got, ref, tol=1e-5)
 
@@ -68,10 +72,14 @@ def test_reference_outputs_other_forward(npm, name):
     """The 4-wave 32x32x2 forward (NPM_TUNE_ATTN_FWD8 = 0) stays selectable and runs the same fixtures."""
     from np_modeling_amd import _C
     d = R.CASES[name]['feat'] // R.CASES[name]['heads']
+    from np_modeling_amd import device as D
     _C.check(_C.lib().npm_set_tuning(17, 0), 'npm_set_tuning')
+    saved = D.ATTN_SAVE_SCORES
+    D.ATTN_SAVE_SCORES = True
     try:
         got, ref = RR.run(npm, name, after_forward=lambda layer: _assert_kernel(npm, f'mha_fwd_kernel D={d} mask=0 scores=1'))
     finally:
+        D.ATTN_SAVE_SCORES = saved
         _C.check(_C.lib().npm_set_tuning(17, 2), 'npm_set_tuning')
     RR.compare(got, ref, tol=1e-5)
 

@@ -20,6 +20,7 @@ ap.add_argument('--s', type=int, default=512)
 ap.add_argument('--d', type=int, default=128)
 ap.add_argument('--reps', type=int, default=5)
 ap.add_argument('--save-scores', action='store_true')
+ap.add_argument('--warm', type=int, default=0, help='untimed launches before the timed ones (reports the median)')
 ap.add_argument('--tune', default='')
 ap.add_argument('--mask', default='', choices=['', 'causal', 'random'], help='attention mask: causal [1,1,S,S] (broadcast over batch and head) or random per (b, h)')
 a = ap.parse_args()
@@ -45,7 +46,29 @@ elif a.mask == 'random':
     mask = D.AttnMask(m, b, h, s, s)
     del m
 print(f'B {b} H {h} S {s} D {d}, mask {a.mask or "none"}, scores {"saved" if a.save_scores else "recomputed"}')
+def launch(name):
+    global ctx, lse, scores
+    if name == 'fwd':
+        ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, mask=mask, save_scores=a.save_scores)
+    else:
+        D.mha_core_bwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), ctx, lse, dctx, Mat(dq, 3 * f), Mat(dk, 3 * f),
+                       Mat(dv, 3 * f), dims, scale, mask=mask, scores=scores)
+
+
 for name in ('fwd', 'bwd'):
+    if a.warm:                                                   # back-to-back launches: the clock a loaded card holds
+        with D.KernelTimer() as t:
+            for rep in range(a.warm + a.reps):
+                launch(name)
+        D.synchronize()
+        per_call = len(t.records) // (a.warm + a.reps)           # the backward books its row-term kernel too
+        calls = [t.records[i * per_call:(i + 1) * per_call] for i in range(a.warm, a.warm + a.reps)]
+        times = [sum(start.elapsed_ms(stop) for _, _, _, start, stop in c) for c in calls]
+        flops = sum(fl for _, fl, _, _, _ in calls[0])
+        ms = float(np.median(times))
+        print(f'mha_core_{name} warm: median {ms:.3f} ms (min {min(times):.3f}) of {a.reps} after {a.warm} untimed  '
+              f'{flops / ms / 1e9:.1f} TF  ({flops / ms / 1e9 / 157.3:.1%} of the fp32-MFMA peak)', flush=True)
+        continue
     for rep in range(a.reps + 1):
         with D.KernelTimer() as t:
             if name == 'fwd':
