@@ -18,14 +18,16 @@ echo "== config bench (f32)"; { timeout -k 10 300 python tools/config_bench.py -
   echo "-- C3 with the K loop of forward / grad_x by taps (NPM_TUNE 16=0: round 3) and by 16-channel chunks (16=1: default), alternating"; for k in 0 1 0 1; do echo "NPM_TUNE=16=$k"; NPM_TUNE=16=$k timeout -k 10 200 python tools/config_bench.py --only C3 --kernels; done; } > "$OUT/${R}_config_bench.log" 2>&1
 echo "== gemm shapes (f32)"; timeout -k 10 200 python tools/gemm_bench.py --tune 10=0 > "$OUT/${R}_gemm_shapes.log" 2>&1
 echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/${R}_rowops.log" 2>&1
-echo "== fused attention core"; { echo "-- saved scores (the default), then recomputing; --reps 12: the card needs a few launches to settle";
-  timeout -k 10 100 python tools/attn_bench.py --save-scores --reps 12; timeout -k 10 100 python tools/attn_bench.py --reps 12;
-  echo "-- the same with mha_bwd8_kernel for everything (NPM_TUNE 14=3), and with round 3's backward kernels (14=1)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --reps 12 --tune 14=3; timeout -k 10 100 python tools/attn_bench.py --reps 12 --tune 14=1;
+echo "== fused attention core"; { echo "-- saved scores (the default from head size 64 up), then recomputing; medians of 15 back-to-back launches after 30 untimed";
+  timeout -k 10 100 python tools/attn_bench.py --save-scores --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --warm 30 --reps 15;
+  echo "-- the 4-wave 32 x 32 x 2 forward (NPM_TUNE 17=0: round 3's), saved scores then recomputing"; timeout -k 10 100 python tools/attn_bench.py --save-scores --warm 30 --reps 15 --tune 17=0; timeout -k 10 100 python tools/attn_bench.py --warm 30 --reps 15 --tune 17=0;
+  echo "-- the same with mha_bwd8_kernel for everything (NPM_TUNE 14=3), and with round 3's backward kernels (14=1)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --warm 30 --reps 15 --tune 14=3; timeout -k 10 100 python tools/attn_bench.py --warm 30 --reps 15 --tune 14=1;
   echo "-- head sizes 64 / 32 / 16 (H x D = 1024), saved scores: default (mha_bwd8_kernel) and round 3's 4-wave backward (14=1)";
-  for d in 64 32 16; do timeout -k 10 100 python tools/attn_bench.py --save-scores --d $d --h $((1024 / d)) --reps 8; timeout -k 10 100 python tools/attn_bench.py --save-scores --d $d --h $((1024 / d)) --reps 8 --tune 14=1; done;
-  echo "-- masked (causal, then random per (b, h)), scores saved (the default) and recomputed; then causal WITHOUT the tile summary (NPM_ATTN_TILE_SKIP=0)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --reps 12; timeout -k 10 100 python tools/attn_bench.py --mask causal --reps 12; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask random --reps 8; NPM_ATTN_TILE_SKIP=0 timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --reps 12;
+  for d in 64 32 16; do timeout -k 10 100 python tools/attn_bench.py --save-scores --d $d --h $((1024 / d)) --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --save-scores --d $d --h $((1024 / d)) --warm 30 --reps 15 --tune 14=1; done;
+  echo "-- masked (causal, then random per (b, h)), scores saved (the default) and recomputed; then causal WITHOUT the tile summary (NPM_ATTN_TILE_SKIP=0)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --mask causal --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask random --warm 30 --reps 15; NPM_ATTN_TILE_SKIP=0 timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --warm 30 --reps 15;
   echo "-- masks of different shapes, saved scores (forward / backward of the 4th repetition)"; timeout -k 10 100 python tools/attn_masks.py;
   echo "-- stamps of the 4-wave kernels, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
+echo "== attention: saved against recomputed scores per head size"; timeout -k 10 400 bash tools/attn_modes.sh > "$OUT/${R}_attn_modes.log" 2>&1
 echo "== parity report (f32)"; timeout -k 10 600 python -c "import sys; sys.path.insert(0, 'tools'); import parity_report; parity_report.main(modes=('f32',))" > "$OUT/${R}_parity_relative_error.log" 2>&1
 echo "== exchange path on one GPU: bench.py without and with a one-rank RCCL communicator (NPM_FORCE_RCCL=1)"
 { echo "bench.py --steps 30 --warmup 5 --no-alt-math --no-configs --no-cpu-baseline, alternating; exchange = rank 0's HIP-event statistics per step";
@@ -54,7 +56,7 @@ python3 profiles/summarize_pmc.py "$OUT"/pmc_FETCH_SIZE/*/*_counter_collection.c
 echo "== TCC request counters of the FFN weight-gradient GEMM (DRAM-destined vs all; L2 hit / miss)"
 tools/pmc/one_shape.sh "ffn_dw_TN M=1024" 10=0 "$OUT/pmc_tn" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RD_UNCACHED_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" > "$OUT/${R}_pmc_tcc_ffn_dw.log" 2>&1
 echo "== SQ / TCC counters of the kernels that are in the step and in the configs"
-{ echo "# tools/pmc/groups.sh: one rocprofv3 --pmc process per counter group, last launch of each kernel"; echo "### attention, C4 shape, saved scores (the default: mha_fwd_kernel, mha_rowterms_kernel, mha_bwd16_kernel)"; tools/pmc/groups.sh "$OUT/pmc_a1" 'mha_' sq -- tools/attn_bench.py --reps 2 --save-scores; echo "### the same under NPM_TUNE 14=3 (mha_bwd8_kernel)"; tools/pmc/groups.sh "$OUT/pmc_a2" 'mha_bwd' sq -- tools/attn_bench.py --reps 2 --save-scores --tune 14=3; } > "$OUT/${R}_pmc_attn_sq.log" 2>&1
+{ echo "# tools/pmc/groups.sh: one rocprofv3 --pmc process per counter group, last launch of each kernel"; echo "### attention, C4 shape, saved scores (the default: mha_fwd8_kernel, mha_rowterms_kernel, mha_bwd16_kernel)"; tools/pmc/groups.sh "$OUT/pmc_a1" 'mha_' sq -- tools/attn_bench.py --reps 2 --save-scores; echo "### the same under NPM_TUNE 14=3 (mha_bwd8_kernel)"; tools/pmc/groups.sh "$OUT/pmc_a2" 'mha_bwd' sq -- tools/attn_bench.py --reps 2 --save-scores --tune 14=3; } > "$OUT/${R}_pmc_attn_sq.log" 2>&1
 { echo "### attention, C4 shape, saved scores: L2 requests that leave the XCD"; tools/pmc/groups.sh "$OUT/pmc_a3" 'mha_' tcc -- tools/attn_bench.py --reps 2 --save-scores; } > "$OUT/${R}_pmc_attn_tcc.log" 2>&1
 { for shp in "ffn1_NN" "ffn_dx_NT M=131072 N=1024" "ffn_dw_TN M=1024"; do echo "### gemm_bench --only '$shp'"; tools/pmc/groups.sh "$OUT/pmc_g" 'sgemm_glds' sq -- tools/gemm_bench.py --only "$shp" --reps 2 --tune 10=0; rm -rf "$OUT/pmc_g"; done; } > "$OUT/${R}_pmc_gemm_sq.log" 2>&1
 { echo "### config_bench --only C3 (conv_fwd_glds_kernel<false> = forward, <true> = grad_x, conv_wgrad_relu_kernel)"; tools/pmc/groups.sh "$OUT/pmc_c1" 'conv_' sq -- tools/config_bench.py --only C3 --min-seconds 0.05; } > "$OUT/${R}_pmc_conv_sq.log" 2>&1
