@@ -1213,6 +1213,7 @@ mha_bwd16_kernel(const MhaArgs p) {
     dma_group<2>(descQ, lds_q, 0u, vq);
     dma_group<2>(descDO, lds_do, 0u, vdo);
 
+    bool scale_pending = false;
     f32x4 Lr_n[2], Dr_n[2];
     auto load_rows = [&](int qfirst) {
 #pragma unroll
@@ -1241,6 +1242,11 @@ mha_bwd16_kernel(const MhaArgs p) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+            if (scale_pending) {                         // the V fragment of a new key block: landed (the counted wait above)
+#pragma unroll
+                for (int cc = 0; cc < 8; ++cc) { vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale; }
+                scale_pending = false;
+            }
             const bool seam = qt + 1 == nqt && kb + 1 < nkb;
             const int nq = qt + 1 < nqt ? qt + 1 : 0;
             const int cur = it & 1, nxt = cur ^ 1;
@@ -1357,10 +1363,8 @@ mha_bwd16_kernel(const MhaArgs p) {
                 dma_group<8>(descK, lds_kb, (unsigned)((kb + 1) * 128 * p.k_pitch * 4), vkb);
                 const int row = (kb + 1) * 128 + kvl;
 #pragma unroll
-                for (int cc = 0; cc < 8; ++cc) {
-                    vf[cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
-                    vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale;
-                }
+                for (int cc = 0; cc < 8; ++cc) vf[cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
+                scale_pending = true;                  // (scaled behind the next tile's barrier: a wait HERE would drain the K block's pieces)
             }
             // ---- dK^T[d, kv] += Q^T[d, q] dS[q, kv]; the dQ stores ride along
             ea[0][0] = ld4(tQ + vb[0]);
