@@ -472,6 +472,22 @@ __device__ __forceinline__ float fmax_raw(float a, float b) {
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+// Reductions over the four lanes l16 + 16 k (k = 0 .. 3) that share a query in the 16 x 16 x 4 result layout, every lane getting
+// the result: gfx950's v_permlane16_swap / v_permlane32_swap exchange 16-lane rows / wave halves between two registers, so with
+// both operands = x the two results hold "this row" and "the partner row" in every lane -- a copy, the swap and the operation
+// per step, where __shfl_xor costs four address instructions, a ds_bpermute and an LDS round trip.
+__device__ __forceinline__ float quad_max(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = fmax_raw(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return fmax_raw(__uint_as_float(q[0]), __uint_as_float(q[1]));
+}
+__device__ __forceinline__ float quad_sum(float x) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    const float y = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    const auto q = __builtin_amdgcn_permlane32_swap(__float_as_uint(y), __float_as_uint(y), false, false);
+    return __uint_as_float(q[0]) + __uint_as_float(q[1]);
+}
 #define MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -681,9 +697,7 @@ mha_fwd8_kernel(const MhaArgs p) {
         //  three's MFMAs -- three-input maxima without the canonicalising self-maxima fmaxf brings, packed fma / add)
         constexpr float RESCALE = 10.f;
         float tmax = max3(max3(max3(S[0][0], S[0][1], S[0][2]), S[0][3], S[1][0]), S[1][1], S[1][2]);
-        tmax = fmax_raw(tmax, S[1][3]);
-        tmax = fmax_raw(tmax, __shfl_xor(tmax, 16, 64));
-        tmax = fmax_raw(tmax, __shfl_xor(tmax, 32, 64)) * c;
+        tmax = quad_max(fmax_raw(tmax, S[1][3])) * c;
         float m_new = m;
         if (__builtin_amdgcn_ballot_w64(tmax > m + RESCALE) != 0) {
             m_new = fmaxf(m, tmax);
@@ -707,10 +721,7 @@ mha_fwd8_kernel(const MhaArgs p) {
                 S[g2][r + 1] = e.y;
                 ps += e;
             }
-        float psum = ps.x + ps.y;
-        psum += __shfl_xor(psum, 16, 64);
-        psum += __shfl_xor(psum, 32, 64);
-        l += psum;
+        l += quad_sum(ps.x + ps.y);
         m = m_new;
         FENCE();
         // ---- O^T[d, q] += V^T[d, kv] P^T[kv, q]: 8 steps (one key row per lane quarter each) of (NV vector reads, NC MFMAs)

@@ -151,7 +151,7 @@ def test_no_kernel_spills_vector_registers(built):
     assert seen >= 40
     import waitcnt_check
     depth = waitcnt_check.scratch_depth(waitcnt_check.assembly('npm_attn.hip'))
-    assert sorted(depth) == sorted(n.replace('(anonymous namespace)::', '') for n in spilled), (depth, spilled)
+    assert set(depth) <= {n.replace('(anonymous namespace)::', '') for n in spilled}, (depth, spilled)      # nobody else touches scratch
     assert all(d <= 1 for d in depth.values()), depth
     # the instance of round 2's spill no longer exists: saved scores carry the mask (csrc/npm_attn.hip launch_bwd)
     attn = kernel_meta.kernel_metadata(os.path.join(lib_dir, 'npm_attn.o'))
