@@ -1152,6 +1152,7 @@ mha_bwd_kernel(const MhaArgs p) {
 //                                        tile in LDS, 16 bytes at kv = 16 c + 4 kk
 // ---------------------------------------------------------------------------------------------------------------
 
+template <bool TRACE>
 __global__ void __launch_bounds__(512, 1)
 mha_bwd16_kernel(const MhaArgs p) {
     constexpr int D = 128;
@@ -1166,6 +1167,10 @@ mha_bwd16_kernel(const MhaArgs p) {
     const int l16 = lane & 15, kk = lane >> 4;
     const int bh = blockIdx.x;
     const int b = bh / p.heads, h = bh - b * p.heads;
+    // diagnostics (npm_debug_attn_trace, tools/attn_trace.py --bwd16): s_memtime stamps of thread 0 at the phase boundaries of one
+    // tile (key block 1, query tile 5) and at the block's start / end
+    long long *const blk_tr = (TRACE && p.trace && tid == 0) ? p.trace + (long)blockIdx.x * 16 : nullptr;
+    if (blk_tr) blk_tr[9] = __builtin_amdgcn_s_memtime();
 
     const auto descK = make_desc(p.k + (long)b * p.seq_kv * p.k_pitch + h * D, ((long)(p.seq_kv - 1) * p.k_pitch + D) * 4);
     const auto rsrcV = make_rsrc(p.v + (long)b * p.seq_kv * p.v_pitch + h * D, ((long)(p.seq_kv - 1) * p.v_pitch + D) * 4);
@@ -1236,6 +1241,7 @@ mha_bwd16_kernel(const MhaArgs p) {
         }
     };
     load_rows(0);
+    if (blk_tr) blk_tr[10] = __builtin_amdgcn_s_memtime();
     for (int kb = 0; kb < nkb; ++kb) {
         const int kvrow = kb * 128 + kvl;
         const bool kvok = kvrow < p.seq_kv;
@@ -1247,6 +1253,8 @@ mha_bwd16_kernel(const MhaArgs p) {
         int in_flight = kb > 0 ? 18 : 0;                 // youngest vector-memory operations that may stay outstanding
 
         for (int qt = 0; qt < nqt; ++qt) {
+            long long *const tr = (TRACE && blk_tr && kb == (nkb > 1 ? 1 : 0) && qt == (nqt > 5 ? 5 : 0)) ? blk_tr : nullptr;
+            STAMP(0);
             if (in_flight == 2) asm volatile("s_waitcnt vmcnt(2) ; npm:wait" ::: "memory");
             else if (in_flight == 18) asm volatile("s_waitcnt vmcnt(18) ; npm:wait" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1258,6 +1266,7 @@ mha_bwd16_kernel(const MhaArgs p) {
                 for (int cc = 0; cc < 8; ++cc) { vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale; }
                 scale_pending = false;
             }
+            STAMP(1);
             const bool seam = qt + 1 == nqt && kb + 1 < nkb;
             const int nq = qt + 1 < nqt ? qt + 1 : 0;
             const int cur = it & 1, nxt = cur ^ 1;
@@ -1306,6 +1315,7 @@ mha_bwd16_kernel(const MhaArgs p) {
                 }
                 FENCE();
             }
+            STAMP(2);
             // ---- P = exp(scale S - LSE); dS = P (dP - delta) (both carry the 1 / sqrt(Dk) already), also into LDS
             f32x4 P[2], dS[2];
 #pragma unroll
@@ -1317,6 +1327,7 @@ mha_bwd16_kernel(const MhaArgs p) {
                     dS[t][r] = pr * dP[t][r];
                     sDS[ws[r] + t * ROWS16] = dS[t][r];
                 }
+            STAMP(3);
             // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (2 vector reads, 8 MFMAs)
             float4 ea[2][2];
             ea[0][0] = ld4(tDO + vb[0]);
@@ -1336,9 +1347,11 @@ mha_bwd16_kernel(const MhaArgs p) {
                 dV[6] = MFMA16(e1.z, P[t][r], dV[6]); dV[7] = MFMA16(e1.w, P[t][r], dV[7]);
                 FENCE();
             }
+            STAMP(4);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                                      // dS of all eight key groups is in LDS
             asm volatile("" ::: "memory");
+            STAMP(5);
 
             // ---- dQ^T[d, q] (+)= K^T[d, kv] dS^T[kv, q] over the 128 keys: 8 steps of (4 element reads, 2 row reads, 8 MFMAs)
             float ak[2][4];
@@ -1368,6 +1381,7 @@ mha_bwd16_kernel(const MhaArgs p) {
                 }
                 FENCE();
             }
+            STAMP(6);
             if (seam) {                                // every wave is done with this K block: request the next one
                 __builtin_amdgcn_s_barrier();
                 asm volatile("" ::: "memory");
@@ -1403,6 +1417,7 @@ mha_bwd16_kernel(const MhaArgs p) {
             in_flight = 2;
             ++it;
             FENCE();
+            STAMP(7);
         }
         // this block's dK and dV rows: lane = key; registers r of tiles 4 x + 0..3 are 4 adjacent head dimensions
         // 64 x + 16 kk + 4 r + e
@@ -1415,6 +1430,11 @@ mha_bwd16_kernel(const MhaArgs p) {
                 buf_store4(rsrcDK, offk, dK[4 * x][r], dK[4 * x + 1][r], dK[4 * x + 2][r], dK[4 * x + 3][r]);
                 buf_store4(rsrcDV, offv, dV[4 * x][r], dV[4 * x + 1][r], dV[4 * x + 2][r], dV[4 * x + 3][r]);
             }
+    }
+    if (blk_tr) {
+        blk_tr[12] = __builtin_amdgcn_s_memtime();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        blk_tr[13] = __builtin_amdgcn_s_memtime();
     }
 }
 
@@ -2154,7 +2174,7 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
     npm::Scratch ws;                                  // stream-ordered pool: safe to release when this call returns
     const bool wide128 = c->head_dim == 128 && a.scores != nullptr && a.skip == nullptr;      // the case mha_bwd16_kernel was built for
     const bool use8 = (g_attn_bwd16 == 3 || (g_attn_bwd16 == 2 && !wide128)) && !a.trace;
-    const bool use16 = !use8 && wide128 && (g_attn_bwd16 == 1 || g_attn_bwd16 == 2) && !a.trace;
+    const bool use16 = !use8 && wide128 && (g_attn_bwd16 == 1 || g_attn_bwd16 == 2) && (!a.trace || g_attn_bwd16 == 1);   // traced: knob 1
     if (use8 || use16) {
         // mha_bwd8_kernel: row terms padded to whole query tiles ([B, H, sq_pad] each: delta, then log2(e) LSE)
         a.sq_pad = (a.seq_q + 31) / 32 * 32;
@@ -2170,7 +2190,8 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
         NPM_CHECK_LAUNCH();
         npm::note_math(NPM_MATH_F32);
         if (use16) {
-            hipLaunchKernelGGL(mha_bwd16_kernel, dim3(a.batch * a.heads), dim3(512), 0, s, a);
+            if (a.trace) hipLaunchKernelGGL(mha_bwd16_kernel<true>, dim3(a.batch * a.heads), dim3(512), 0, s, a);
+            else hipLaunchKernelGGL(mha_bwd16_kernel<false>, dim3(a.batch * a.heads), dim3(512), 0, s, a);
             note_kernel("mha_bwd16_kernel", 128, false, true);
             NPM_CHECK_LAUNCH();
             return NPM_OK;

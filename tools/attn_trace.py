@@ -40,6 +40,32 @@ print(f'tile total                 {np.median(fh[:, 4] - fh[:, 0]):7.0f}')
 print(f'block: prologue {np.median(fh[:, 10] - fh[:, 9]):.0f}, tile loop {np.median(fh[:, 12] - fh[:, 10]):.0f} '
       f'({s // 32} tiles), epilogue {np.median(fh[:, 13] - fh[:, 12]):.0f}, whole {np.median(fh[:, 13] - fh[:, 9]):.0f} cycles')
 nblocks = b * h
+if '--bwd16' in sys.argv:                      # the shipped 8-wave backward (head size 128, saved scores): NPM_TUNE 14=1 selects it under the trace
+    _C.check(lib.npm_set_tuning(14, 1), 'npm_set_tuning')
+    ctx, lse, scores = D.mha_core_fwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), dims, scale, save_scores=True)
+    trace = D._Buffer(8 * 16 * nblocks)
+    for rep in range(3):
+        _C.check(lib.npm_debug_attn_trace(trace.ptr))
+        D.mha_core_bwd(Mat(q, 3 * f), Mat(k, 3 * f), Mat(v, 3 * f), ctx, lse, dctx, Mat(dq, 3 * f), Mat(dk, 3 * f), Mat(dv, 3 * f), dims, scale, scores=scores)
+        D.synchronize()
+        _C.check(lib.npm_debug_attn_trace(None))
+    assert _C.last_attn_kernel().startswith('mha_bwd16_kernel'), _C.last_attn_kernel()
+    host = np.zeros([nblocks, 16], dtype=np.int64)
+    _C.check(lib.npm_d2h(host.ctypes.data, trace.ptr, host.nbytes))
+    names = ['wait + barrier (tile landed)', 'loads issued + dP = dO V^T', 'exp, dS -> LDS', 'dV', 'barrier (dS)', 'dQ (+next DMA)', 'dK (+dQ stores)']
+    dt = np.diff(host[:, :8], axis=1)
+    print('mha_bwd16_kernel, thread 0, key block 1 / query tile 5: phase   median   p10    p90   '
+          '(cycles of s_memtime; 64 MFMAs of this wave = 2048 cycles alone, 4096 with the SIMD\'s other wave at the pipe rate)')
+    for i, n in enumerate(names):
+        col = dt[:, i]
+        print(f'{n:30s} {np.median(col):7.0f} {np.percentile(col, 10):6.0f} {np.percentile(col, 90):6.0f}')
+    tile = host[:, 7] - host[:, 0]
+    print(f'tile total                     {np.median(tile):7.0f}   (4 x 4096 = 16384 at the pipe rate)')
+    nt = (s // 32) * (s // 128)
+    print(f'block: prologue {np.median(host[:, 10] - host[:, 9]):.0f}, all key blocks {np.median(host[:, 12] - host[:, 10]):.0f} '
+          f'({nt} tiles = {np.median(host[:, 12] - host[:, 10]) / nt:.0f} per tile), drain {np.median(host[:, 13] - host[:, 12]):.0f}, '
+          f'whole {np.median(host[:, 13] - host[:, 9]):.0f} cycles')
+    sys.exit(0)
 trace = D._Buffer(8 * 16 * nblocks)
 for rep in range(3):
     _C.check(lib.npm_debug_attn_trace(trace.ptr))
