@@ -27,7 +27,7 @@ echo "== fused attention core"; { echo "-- saved scores (the default from head s
   echo "-- masked (causal, then random per (b, h)), scores saved (the default) and recomputed; then causal WITHOUT the tile summary (NPM_ATTN_TILE_SKIP=0)"; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --mask causal --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --save-scores --mask random --warm 30 --reps 15; NPM_ATTN_TILE_SKIP=0 timeout -k 10 100 python tools/attn_bench.py --save-scores --mask causal --warm 30 --reps 15;
   echo "-- masks of different shapes, saved scores (forward / backward of the 4th repetition)"; timeout -k 10 100 python tools/attn_masks.py;
   echo "-- stamps of the 4-wave kernels, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
-echo "== phase stamps of the shipped backward (diagnostic instance)"; timeout -k 10 200 python tools/attn_trace.py --bwd16 2>&1 | sed -n "/mha_bwd16_kernel, thread 0/,\$p" > "$OUT/${R}_attn_bwd16_phases.log"
+echo "== phase stamps of the shipped backward (diagnostic instance)"; timeout -k 10 200 python tools/attn_trace.py --bwd16 2>&1 | sed -n "/mha_bwd16_kernel, thread 0/,\$p" > "$OUT/${R}_attn_bwd16_phases_trace.log"   # (profiles/r04_attn_bwd16_phases.log = this + two experiments appended by hand)
 echo "== attention: saved against recomputed scores per head size"; timeout -k 10 400 bash tools/attn_modes.sh > "$OUT/${R}_attn_modes.log" 2>&1
 echo "== parity report (f32)"; timeout -k 10 600 python -c "import sys; sys.path.insert(0, 'tools'); import parity_report; parity_report.main(modes=('f32',))" > "$OUT/${R}_parity_relative_error.log" 2>&1
 echo "== exchange path on one GPU: bench.py without and with a one-rank RCCL communicator (NPM_FORCE_RCCL=1)"
