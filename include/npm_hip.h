@@ -134,6 +134,7 @@ enum {
     NPM_TUNE_KSYNC = 15,             /* K tiles between the soft rendezvous of the co-resident split-K blocks of the fused Conv2D filter gradient: a power of two, default 128; 0 off */
     NPM_TUNE_CONV_KORDER = 16,       /* Conv2D forward / grad_x K loop: 1 (default) the k k taps of one 16-channel chunk back to back (the lines a tap fetched are still in L2 when its neighbour wants them: grad_x of C3 reads 13.8 instead of 82 GB past the L2s, +4 %), 0 taps outermost (kk = tap C + c) */
     NPM_TUNE_ATTN_FWD8 = 17,         /* attention forward: 2 mha_fwd8_kernel (8 waves per block on the 16x16x4 MFMA, four waves per SIMD) for every head size; 1 below head size 128 only; 0 the 4-wave 32x32x2 mha_fwd_kernel always */
+    NPM_TUNE_GEMM_SPLIT_GENS = 18,   /* split-K of tall-K products (weight gradients): 1 (default) for A-heavy products that also sum A's columns, a K range longer than 768 K tiles is cut further when that makes whole generations of resident blocks (3 x 4 per CU: the packed q/k/v weight gradient 6.00 -> 5.71 ms); 0 one generation of three blocks per CU always (round 3) */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
     NPM_TUNE_GEMM_ABLATE = 99
 };

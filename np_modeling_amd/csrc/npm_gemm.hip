@@ -50,6 +50,7 @@ struct GemmArgs {
 
 int g_pipe = 2;       // tuning knobs (npm_set_tuning); 2 = LDS-DMA pipeline where eligible
 int g_group_m = 8;
+int g_split_gens = 1;             // NPM_TUNE_GEMM_SPLIT_GENS
 int g_ablate = 0;
 int g_wave_prio = 0;               // NPM_TUNE_GEMM_WAVE_PRIO
 int g_math = 0;                    // NPM_TUNE_GEMM_MATH
@@ -463,6 +464,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
         case NPM_TUNE_KSYNC: npm::set_ksync_every(value); return NPM_OK;
         case NPM_TUNE_CONV_KORDER: return npm_conv_set_korder(value);
         case NPM_TUNE_STREAM_NT: npm::set_stream_nt(value); return NPM_OK;
+        case NPM_TUNE_GEMM_SPLIT_GENS: g_split_gens = value != 0; return NPM_OK;
         default: return npm::fail(NPM_E_BAD_ARGUMENT, "npm_set_tuning: unknown knob %d", knob);
     }
 }
@@ -542,7 +544,10 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
-        splits = pick_splits(tiles, nkt, npm::ctx().num_cus, 0, g_math >= 2 ? 2 : g_math == 1 ? 3 : 4);
+        // (several generations of shorter K ranges: measured to pay for the A-heavy products that also sum A's columns -- the packed
+        //  q/k/v weight gradient [3F, F] -- and to cost 0.3 ms per step on the FFN weight gradients, which sum B's: profiles/r04_splitk_sweep.log)
+        const bool more_generations = g_math == 0 && g_split_gens && want_asum && a.tiles_m > a.tiles_n;
+        splits = pick_splits(tiles, nkt, npm::ctx().num_cus, 0, g_math >= 2 ? 2 : g_math == 1 ? 3 : 4, more_generations ? 1 : 0);
     }
     if (!linear_epi) splits = 1;
     if (splits > nkt) splits = nkt > 0 ? nkt : 1;

@@ -690,7 +690,7 @@ __device__ __forceinline__ void ksync_wait(const KSync &k, int kt) {
 // long, so the launch lasts as long as the fullest CU: cost(s) = ceil(tiles * s / CUs) / s.  Candidates leave the
 // fullest CU with `resident` or `resident - 1` blocks (fewer cannot keep the matrix pipe busy, more would queue a
 // second generation).  `force_per_cu` > 0 pins the blocks-per-CU target.
-inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0, int resident = 4) {
+inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0, int resident = 4, int generations = 0) {
     const long max_s = nkt / 8;
     int best = 1;
     double best_cost = 1e30;
@@ -707,6 +707,19 @@ inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0, int 
         if (s < 1) s = 1;
         const double cost = (double)((tiles * s + cus - 1) / cus) / (double)s;
         if (cost < best_cost * (1.0 - 1e-6)) { best_cost = cost; best = (int)s; }
+    }
+    // Long K ranges (round 4, `generations` > 0): the blocks of one generation stream the same operand panels through their XCD's
+    // L2 and drift apart over a thousand K tiles (the packed q/k/v weight gradient, 192 tiles x 4 splits of 1024 K tiles of 32:
+    // 6.00 ms; x 16 splits of 256: 5.71 ms).  When the chosen range is longer than 768 K tiles and an exact number of FULL
+    // generations (`resident` blocks on every CU, 3 then 2 of them) exists with at least 128 K tiles per block, take that.
+    if (generations > 0 && force_per_cu == 0 && nkt / best > 768) {
+        for (int gens = 3; gens >= 2; --gens) {
+            const long blocks = (long)resident * gens * cus;
+            if (blocks % tiles) continue;
+            const long s = blocks / tiles;
+            if (s <= best || s > max_s || nkt / s < 128) continue;
+            return (int)s;
+        }
     }
     return best;
 }

@@ -59,6 +59,18 @@ def main():
         'pv_NN  2048x(512x128x512)': (2.0 * B * H * S * S * Dk, lambda: D.gemm(S, Dk, S, Mat(scores, S, H * S * S, S * S), Mat(x, F, S * F, Dk), Mat(out_f, F, S * F, Dk), batch=(B, H))),
         'dv_TN  2048x(512x128x512)': (2.0 * B * H * S * S * Dk, lambda: D.gemm(S, Dk, S, Mat(scores, S, H * S * S, S * S), Mat(x, F, S * F, Dk), Mat(out_f, F, S * F, Dk), trans_a=True, batch=(B, H))),
     }
+    # the packed q/k/v weight gradient of self-attention (layers/attentions.py: dqkv^T x with the bias gradients as column sums of
+    # dqkv), as ONE product over the packed 3F axis and as three products over its thirds (row pitch 3F)
+    dqkv = hbuf                                   # [M, 3F] lives in the first 3F/U of the [M, U] buffer's rows: view with pitch 3 F
+    db3 = D.empty([3 * F])
+
+    def qkv_three():
+        for i in range(3):
+            D.gemm(F, F, M, Mat(dqkv.flat_view(i * F, [dqkv.size - i * F]), 3 * F), Mat(x, F), Mat(dw.flat_view(i * F * F, [F * F]), F), trans_a=True,
+                   asum_out=db3.flat_view(i * F, [F]))
+    shapes['qkv_dw_TN M=3072 N=1024 K=131072 (one product)'] = (2.0 * M * 3 * F * F, lambda: D.gemm(3 * F, F, M, Mat(dqkv, 3 * F), Mat(x, F), Mat(dw, F), trans_a=True, asum_out=db3))
+    shapes['qkv_dw_TN 3 x (M=1024 N=1024 K=131072, lda 3072)'] = (2.0 * M * 3 * F * F, qkv_three)
+    shapes['out_dw_TN M=1024 N=1024 K=131072 + column sums'] = (2.0 * M * F * F, lambda: D.gemm(F, F, M, Mat(out_f, F), Mat(x, F), Mat(dw, F), trans_a=True, asum_out=db3.flat_view(0, [F])))
     n2 = 4096            # BASELINE configs[1]: Dense 4096 -> 4096, batch 4096 (one generation of 1024 tiles)
     a2, b2, c2 = buf(n2 * n2), buf(n2 * n2), D.empty([n2 * n2])
     shapes['c2_fwd_NN M=4096 N=4096 K=4096'] = (2.0 * n2 ** 3, lambda: D.gemm(n2, n2, n2, Mat(a2, n2), Mat(b2, n2), Mat(c2, n2)))
