@@ -92,8 +92,9 @@ def build_config(name, npm, D, rng, conv_batch=256):
         x = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32))
         dy = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01))
         layer(x)
-        for n in ('_wq', '_wk', '_wv', '_wo'):
-            setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
+        for n in ('_wq', '_wk', '_wv', '_wo'):     # softmaxes that are not one-hot; scaled IN PLACE: rebinding a parameter to a new
+            w = getattr(layer, n)                   # array would take wq / wk / wv out of their packed buffer (three projection GEMMs
+            w *= np.float32(1.0 / 32)               # instead of one, layers/attentions.py _params_adjacent)
         label = 'MultiHeadAttention d_model=1024 heads=8 seq=512 fwd+bwd+SGD, batch 256 (BASELINE.json configs[3])'
         flops = 12 * 2.0 * b * s * f * f + 6 * 2.0 * b * s * s * f
     elif name in ('C4M', 'C4D64'):
@@ -104,8 +105,9 @@ def build_config(name, npm, D, rng, conv_batch=256):
         dy = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01))
         mask = D.AttnMask(np.tril(np.ones([s, s], dtype=bool))[None, None], b, h, s, s) if name == 'C4M' else None   # made once
         layer(x)
-        for n in ('_wq', '_wk', '_wv', '_wo'):
-            setattr(layer, n, (np.asarray(getattr(layer, n)) / 32).astype(np.float32))
+        for n in ('_wq', '_wk', '_wv', '_wo'):     # softmaxes that are not one-hot; scaled IN PLACE: rebinding a parameter to a new
+            w = getattr(layer, n)                   # array would take wq / wk / wv out of their packed buffer (three projection GEMMs
+            w *= np.float32(1.0 / 32)               # instead of one, layers/attentions.py _params_adjacent)
         label = (f'MultiHeadAttention d_model=1024 heads={h} seq=512 fwd+bwd+SGD, batch 256' +
                  (', CAUSAL mask (reference attentions.py:105-107; TFLOP/s count the UNMASKED products: above the peak means '
                   'skipped tiles)' if mask is not None else '') + ' (not a BASELINE.json config)')
