@@ -692,6 +692,10 @@ __device__ __forceinline__ void ksync_wait(const KSync &k, int kt) {
 // second generation).  `force_per_cu` > 0 pins the blocks-per-CU target.
 inline int pick_splits(long tiles, int nkt, long cus, int force_per_cu = 0, int resident = 4, int generations = 0) {
     const long max_s = nkt / 8;
+    if (force_per_cu > resident) {                       // several generations of `resident` blocks, pinned (experiments)
+        const long s = (long)force_per_cu * cus / tiles;
+        return (int)(s < 1 ? 1 : s > max_s ? max_s : s);
+    }
     int best = 1;
     double best_cost = 1e30;
     // candidates in order of preference: 3 blocks per CU where that many fit (measured on the FFN weight gradients,
