@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define NPM_ABI_VERSION 1
+#define NPM_ABI_VERSION 2      /* 2: npm_mha_core gained tile_summary .. summary_all_offset, npm_comm_exchange_stats last_allreduce_ms / dropped */
 
 enum {
     NPM_OK = 0,
@@ -260,8 +260,11 @@ typedef struct npm_mha_core {
      * of 128), bit w set when some position of the 32 x 16 sub-tile (keys 16 w .. 16 w + 15 of the block) is allowed; byte
      * (qt, kb) of plane (b, h) at tile_summary[b * summary_stride_b + h * summary_stride_h + qt * ceil(seq_kv / 128) + kb]
      * (a stride of 0 broadcasts, like the mask's).  Forward and backward then skip tiles without an allowed position: the
-     * results are the same as without it; positions of `scores` inside skipped tiles are left unwritten (the backward never
-     * reads them).  Used for seq_q, seq_kv <= 2048; longer sequences run unskipped. */
+     * results are the same as without it -- including the NaNs of a query row with NO allowed key (np.where(mask, s, -inf) then
+     * softmax: that row of ctx and dq, and through P = NaN every dk / dv row of its (batch, head)): npm_mha_mask_summary marks
+     * every tile of a mask plane that has such a row as "visit", so such planes are simply not skipped.  Positions of `scores`
+     * inside skipped tiles are left unwritten (the backward never reads them).  Used for seq_q, seq_kv <= 2048; longer
+     * sequences, and calls made while npm_debug_attn_trace is active, run unskipped. */
     const uint8_t *tile_summary; int64_t summary_stride_b, summary_stride_h;
     int64_t summary_all_offset;   /* bytes from a tile's "some position allowed" byte to its "every position allowed" byte (the second
                                      half of what npm_mha_mask_summary writes: planes_b * planes_h * tiles bytes later); 0 = not given.
@@ -270,7 +273,8 @@ typedef struct npm_mha_core {
 int npm_mha_core_supported(int head_dim);          /* 1 when npm_mha_core_fwd/bwd take this head dimension */
 int npm_mha_core_fwd(const npm_mha_core *c);
 int npm_mha_core_bwd(const npm_mha_core *c);
-/* summary[2][plane_b][plane_h][ceil(seq_q / 32)][ceil(seq_kv / 128)] (first the "some position allowed" bytes, then, in the
+/* A plane (b, h) with a query row that has no allowed key at all gets 0xFF in every "some position allowed" byte (see above).
+ * summary[2][plane_b][plane_h][ceil(seq_q / 32)][ceil(seq_kv / 128)] (first the "some position allowed" bytes, then, in the
  * same order, the "every position inside the tensors allowed" bytes) of a byte mask laid out like npm_mha_core's (element
  * (b, h, i, j) at mask[b * stride_b + h * stride_h + i * stride_q + j]); planes_b / planes_h = how many distinct planes the
  * mask has along batch and head (1 where it broadcasts).  np.where(mask, scaled, -inf) of attentions.py:105-107 skips

@@ -60,23 +60,35 @@ struct MhaArgs {
     long long *trace;                 // diagnostics (npm_debug_attn_trace): 16 s_memtime stamps per block, or null
 };
 
-// [rows][D] fp32 tile in LDS whose 16-byte chunk c of row r sits at chunk position c ^ (r & SWZ).  Rows read with
-// one ds_read_b128 per lane (lane = row: the K-major MFMA operand) are conflict-free (16 consecutive rows hit 16
-// different positions), and so are ds_read_b32 along a row (the XOR permutes chunks inside one 64-byte-aligned group).
+// [rows][D] fp32 tile in LDS whose 16-byte chunk c of row r sits at chunk position c ^ sw(r).  sw is a LINEAR function of the
+// row's low four bits, chosen per head size so that every access pattern of the kernels below is free of bank conflicts
+// (tools/lds_bank_model.py models them against the bank rules of MI355X_MICROARCH.md, section LDS):
+//   * rows read with one ds_read_b128 per lane (lane = row: the K-major MFMA operand), 16 x 16 x 4 and 32 x 32 x 2 layouts;
+//   * COLUMN vectors (a lane reads VW adjacent columns of row 4 kk + j: the A operand of dV^T / dK^T / O^T) -- with the plain
+//     sw(r) = r & 15 of rounds 2-4 rows j and 4 + j of one ds_read_b128 lane group landed on the same 16 chunk positions: every
+//     such read was a 2-way conflict, 27.6 % of the LDS cycles of mha_bwd16_kernel and 33 % of mha_fwd8_kernel's
+//     (profiles/r04_pmc_attn_sq.log; the model reproduces both figures).  Position bit 3 = row bit 3 XOR row bit 2 separates them;
+//   * ds_read_b32 / ds_write_b32 along a row.
+// Rows shorter than a 256-byte bank line (D = 32, 16) put 2 / 4 rows on one line, so their positions come from row bits 1.. / 2..
 template <int D>
 struct Tile {
     static constexpr int CPR = D / 4;                           // chunks per row
     static constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
+    __host__ __device__ static constexpr int sw(int row) {
+        return D >= 64 ? ((row & 15) ^ ((row & 4) << 1))
+             : D == 32 ? (((row >> 1) & 3) | ((((row >> 2) ^ (row >> 3)) & 1) << 2))
+                       : (((row >> 2) & 1) | ((((row >> 2) ^ (row >> 3)) & 1) << 1));
+    }
     static constexpr int PIECE_ROWS = 256 / D;                  // rows per 1 KiB DMA piece
     static constexpr int NG = D / 8;                            // k groups of 8 along a row
     static constexpr int NB = NG < 8 ? NG : 8;                  // lane-dependent bases of the row reads
     static_assert(D == 16 || D == 32 || D == 64 || D == 128, "head dim");
-    __device__ static __forceinline__ int chunk(int row, int c) { return row * D + ((c ^ (row & SWZ)) << 2); }
-    __device__ static __forceinline__ int elem(int row, int col) { return row * D + ((((col >> 2) ^ (row & SWZ)) << 2) | (col & 3)); }
+    __device__ static __forceinline__ int chunk(int row, int c) { return row * D + ((c ^ sw(row)) << 2); }
+    __device__ static __forceinline__ int elem(int row, int col) { return row * D + ((((col >> 2) ^ sw(row)) << 2) | (col & 3)); }
     // byte offset (inside a [rows][pitch] global matrix) that lane `lane` of DMA piece `piece` copies from
     __device__ static __forceinline__ unsigned src(int lane, int piece, long pitch) {
         const int row = piece * PIECE_ROWS + lane / CPR;
-        const int c = (lane % CPR) ^ (row & SWZ);
+        const int c = (lane % CPR) ^ sw(row);
         return (unsigned)((row * pitch + c * 4) * 4);
     }
     // Addresses as (lane-dependent base register) + (compile-time immediate), so that a fully unrolled phase costs a
@@ -99,12 +111,6 @@ struct Tile {
             for (int k = 0; k < 4; ++k) vb[par][k] = elem(4 * half + k + 8 * par, col);
     }
     __device__ static constexpr int vec_imm(int r) { return 16 * (r >> 3) * D; }
-    // Element read (ds_read_b32) of row 4 half + k + 8 rr, column 32 t + col (col < 32): eb[k] + elem_imm(t, rr).
-    __device__ static __forceinline__ void elem_bases(int half, int col, int (&eb)[4]) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) eb[k] = elem(4 * half + k, col);
-    }
-    __device__ static constexpr int elem_imm(int t, int rr) { return 8 * rr * D + (((8 * t) ^ ((8 * rr) & SWZ)) << 2); }
 };
 
 __device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
@@ -560,7 +566,13 @@ mha_fwd8_kernel(const MhaArgs p) {
         if (qt == unit) break;
         __syncthreads();
     }
-    const int qrow = qt * 128 + wave * 16 + l16;                                 // this lane's query (shared by its four lanes kk)
+    // The lane index is made afresh per query tile (v_mbcnt inside an opaque asm): hipcc hoists everything it can derive from
+    // threadIdx out of the rep loop, and in the masked instances at D = 128 -- which sit at the 128-register limit of four waves
+    // per SIMD -- what it kept alive across the key-tile loop for the second query tile (this lane's query row, the byte
+    // addresses and shifts of the summary look-up below: two 64-bit pointers and three words) went to scratch.
+    int ln;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+    const int qrow = qt * 128 + wave * 16 + (ln & 15);                           // this lane's query (shared by its four lanes kk)
     const bool qok = qrow < p.seq_q;
     const int mvoff = qok ? (int)(qrow * p.mask_sq + 4 * kk) : OOB;              // mask bytes: this query's row, keys 4 kk ..
     const int svoff = qok ? (int)(((long)qrow * p.seq_kv + 4 * kk) * 4) : OOB;   // saved scores, the same way
@@ -572,16 +584,16 @@ mha_fwd8_kernel(const MhaArgs p) {
         const unsigned char *sk = p.skip + b * p.skip_sb + h * p.skip_sh;
         unsigned any = 0, own = 0, full = 0;
         const int mytile = 4 * qt + (wave >> 1);                                 // the summary row (32 queries) of this wave's 16
-        if (lane < nt) {
+        if (ln < nt) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int qtile = 4 * qt + i;
-                const unsigned bits = qtile * 32 < p.seq_q ? (sk[(long)qtile * p.skip_nkb + (lane >> 2)] >> (2 * (lane & 3))) & 3u : 0u;
+                const unsigned bits = qtile * 32 < p.seq_q ? (sk[(long)qtile * p.skip_nkb + (ln >> 2)] >> (2 * (ln & 3))) & 3u : 0u;
                 any |= bits;
                 if (qtile == mytile) own = bits;
             }
             if (p.skip_all && mytile * 32 < p.seq_q)
-                full = (sk[p.skip_all + (long)mytile * p.skip_nkb + (lane >> 2)] >> (2 * (lane & 3))) & 3u;
+                full = (sk[p.skip_all + (long)mytile * p.skip_nkb + (ln >> 2)] >> (2 * (ln & 3))) & 3u;
         }
         act = __builtin_amdgcn_ballot_w64(any != 0);
         mine = __builtin_amdgcn_ballot_w64(own != 0);
@@ -855,15 +867,13 @@ mha_bwd_kernel(const MhaArgs p) {
     T::vec_bases(half, l32, vb);                         // column vectors of the Q / dO tiles
     TS::row_bases(l32, half, rbs);                       // rows of the dS tile
     {
-        int eb[4], es[4];
-        T::elem_bases(half, dcol, eb);
-        TS::elem_bases(half, l32, es);
 #pragma unroll
         for (int par = 0; par < 2; ++par)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
-                ebk[par][k] = eb[k] + (((8 * wave) ^ ((8 * par) & T::SWZ)) << 2);        // K block, columns 32 wave + ..
-                ebs[par][k] = es[k] + (((8 * wave) ^ ((8 * par) & TS::SWZ)) << 2);       // dS tile, columns 32 wave + ..
+                // row 4 half + k + 8 par (the 8 par rows are added as an immediate at the read), columns 32 wave + ..
+                ebk[par][k] = T::elem(4 * half + k + 8 * par, 32 * wave + dcol) - 8 * par * D;       // K block
+                ebs[par][k] = TS::elem(4 * half + k + 8 * par, 32 * wave + l32) - 8 * par * 128;     // dS tile
             }
     }
     const float *sKW = sKB + 32 * wave * D;              // this wave's 32 keys of the K block
@@ -1994,6 +2004,33 @@ mha_mask_summary_kernel(const unsigned char *__restrict__ mask, long sb, long sh
     }
 }
 
+// Rows without ANY allowed key.  np.where(mask, scaled, -inf) followed by the softmax (attentions.py:105-110) makes such a row NaN,
+// and through P = NaN its dq row and EVERY dk / dv row of its (batch, head) -- which is what the kernels compute when they visit
+// every tile.  Skipping must not change results (a skipped tile would leave that row's dq zero and the keys of skipped blocks
+// clean), so a plane that has such a row is not skipped at all: every "some position allowed" byte of the plane is set to 0xFF
+// (the "every position allowed" bytes stay as computed).  One block per plane, after mha_mask_summary_kernel in stream order.
+__global__ void __launch_bounds__(256)
+mha_mask_nokey_rows_kernel(const unsigned char *__restrict__ mask, long sb, long sh, long sq, int nh, int seq_q, int seq_kv,
+                           int tiles_per_plane, unsigned char *__restrict__ out) {
+    __shared__ int empty_row;
+    const long plane = blockIdx.x;
+    const int hh = (int)(plane % nh);
+    const long bb = plane / nh;
+    if (threadIdx.x == 0) empty_row = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned char *base = mask + bb * sb + hh * sh;
+    for (int row = wave; row < seq_q; row += 4) {
+        const unsigned char *src = base + (long)row * sq;
+        unsigned any = 0;
+        for (int k = lane; k < seq_kv; k += 64) any |= src[k];
+        if (__builtin_amdgcn_ballot_w64(any != 0) == 0 && lane == 0) empty_row = 1;
+    }
+    __syncthreads();
+    if (empty_row)
+        for (int i = threadIdx.x; i < tiles_per_plane; i += 256) out[plane * tiles_per_plane + i] = 0xFF;
+}
+
 // The s_memtime stamps of npm_debug_attn_trace live in instances of their own (D = 128, no mask): the product
 // instances carry no trace code at all (each stamp is an exec-masked branch in a loop where every instruction counts).
 template <int D, bool MASK, bool SAVE>
@@ -2082,7 +2119,9 @@ int fill_args(const npm_mha_core *c, bool backward, MhaArgs &a) {
     a.scores = c->scores;
     // tile summary: the kernels keep one bit per tile in a 64-bit scalar, so sequences beyond 2048 just do not skip
     // (and the older backward kernels know nothing of it: with them selected the forward must write every score)
-    if (c->mask && c->tile_summary && c->seq_q <= 2048 && c->seq_kv <= 2048 && g_attn_bwd16 >= 2) {
+    // (nor do the diagnostic instances of npm_debug_attn_trace: with a trace buffer set the backward falls through to the 4-wave
+    //  kernel, which reads every saved score -- the forward must then have written every one)
+    if (c->mask && c->tile_summary && c->seq_q <= 2048 && c->seq_kv <= 2048 && g_attn_bwd16 >= 2 && !g_attn_trace) {
         NPM_ARG(c->summary_stride_b >= 0 && c->summary_stride_h >= 0);
         a.skip = c->tile_summary;
         a.skip_sb = c->summary_stride_b;
@@ -2135,6 +2174,9 @@ extern "C" int npm_mha_mask_summary(const uint8_t *mask, int64_t stride_b, int64
     NPM_ARG(blocks < (1L << 31));
     hipLaunchKernelGGL(mha_mask_summary_kernel, dim3((int)blocks), dim3(256), 0, npm::ctx().stream, mask, (long)stride_b, (long)stride_h,
                        (long)stride_q, planes_h, seq_q, seq_kv, nqt, nkb, blocks, summary);
+    NPM_CHECK_LAUNCH();
+    hipLaunchKernelGGL(mha_mask_nokey_rows_kernel, dim3(planes_b * planes_h), dim3(256), 0, npm::ctx().stream, mask, (long)stride_b,
+                       (long)stride_h, (long)stride_q, planes_h, seq_q, seq_kv, nqt * nkb, summary);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }

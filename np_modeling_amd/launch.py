@@ -60,6 +60,27 @@ def die_with_parent() -> bool:
     return bool(prctl) and prctl(1, int(signal.SIGTERM), 0, 0, 0) == 0            # PR_SET_PDEATHSIG = 1
 
 
+def die_with_launcher() -> bool:
+    """What a rank does at start-up (np_modeling_amd/parallel.py init): arm PR_SET_PDEATHSIG again -- but only when THIS
+    package's launcher started the rank (it exports its pid as NPM_LAUNCHER_PID, and the rank's parent is that process).  A
+    rank started from a shell or a wrapper that exits on purpose (nohup, setsid, ``bash -c '... &'``) must not be killed
+    when that parent goes away.  The call can also come too late (no signal is delivered for a parent that died before it):
+    the parent is checked again afterwards and the rank ends itself.  NPM_DIE_WITH_PARENT=0 switches it off."""
+    if os.environ.get('NPM_DIE_WITH_PARENT', '1') == '0':
+        return False
+    launcher = os.environ.get('NPM_LAUNCHER_PID', '')
+    if not launcher.isdigit():
+        return False
+    if os.getppid() != int(launcher):
+        # started through an intermediate process (its lifetime is not ours to tie to), or the launcher is gone already --
+        # in which case the request armed between fork and exec (_child_setup) has delivered its signal
+        return False
+    armed = die_with_parent()
+    if os.getppid() != int(launcher):               # it died between the check and the prctl: no signal will come
+        os._exit(143)
+    return armed
+
+
 def _child_setup() -> None:
     """Between fork and exec.  The launcher blocks its handled signals around each spawn (a signal must find every
     started rank in its list); the block is inherited across exec, so the child lifts it again."""
@@ -132,10 +153,19 @@ def bind_to_gpu_cpus(local_rank: int, sysfs: str = '/sys') -> dict:
     return info
 
 
-def rank_environment(rank: int, world: int, rendezvous_file: str, base: Optional[Dict[str, str]] = None) -> Dict[str, str]:
+def new_launch_token() -> str:
+    """A value no other launch has: every rank of one spawn_ranks() call gets the same one (NPM_LAUNCH_TOKEN), and the
+    rendezvous file carries it (np_modeling_amd/parallel.py _pack_id)."""
+    import uuid
+    return uuid.uuid4().hex
+
+
+def rank_environment(rank: int, world: int, rendezvous_file: str, base: Optional[Dict[str, str]] = None,
+                     token: Optional[str] = None) -> Dict[str, str]:
     env = dict(os.environ if base is None else base)
     env.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), LOCAL_WORLD_SIZE=str(world),
-               NPM_RENDEZVOUS_FILE=rendezvous_file)
+               NPM_RENDEZVOUS_FILE=rendezvous_file, NPM_LAUNCH_TOKEN=token or new_launch_token(),
+               NPM_LAUNCHER_PID=str(os.getpid()))
     env.setdefault('MASTER_ADDR', '127.0.0.1')
     # RCCL maps its peers' buffers through HIP IPC handles; this pool's host driver implements the dmabuf IPC mode
     # only, and with the legacy mode (the ROCr default) hipIpcGetMemHandle returns "invalid argument" (documented
@@ -155,6 +185,7 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
         _C.build_if_missing()                     # make only; nothing here touches a device
     workdir = tempfile.mkdtemp(prefix='npm_launch_')
     rendezvous = os.path.join(workdir, 'rccl_id')
+    token = new_launch_token()                    # one per launch: a file of any other launch is not this one's
     procs: List[subprocess.Popen] = []
     code = 0
 
@@ -175,7 +206,7 @@ def spawn_ranks(n: int, argv: Sequence[str], *, build: bool = True, poll: float 
             # list: hold it until the child is recorded (the child lifts the inherited block, _child_setup)
             blocked = signal.pthread_sigmask(signal.SIG_BLOCK, handled) if previous else None
             try:
-                procs.append(subprocess.Popen(list(argv), env=rank_environment(rank, n, rendezvous, env),
+                procs.append(subprocess.Popen(list(argv), env=rank_environment(rank, n, rendezvous, env, token),
                                               stdout=None if rank == 0 else sys.stderr, preexec_fn=_child_setup))
             finally:
                 if blocked is not None:

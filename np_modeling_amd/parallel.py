@@ -126,29 +126,51 @@ _REDUCE_OP = AVG
 PLACEMENT: dict = {'bound': False, 'reason': 'single process'}      # what init() did about CPU affinity (launch.bind_to_gpu_cpus)
 
 
+def _job_id() -> str:
+    """A per-job identifier an external launcher or scheduler exports (every rank of the job sees the same one, a later
+    job another): torch.distributed.run's ``--rdzv-id`` (its default 'none' is not one) or the SLURM job id."""
+    for var in ('TORCHELASTIC_RUN_ID', 'SLURM_JOB_ID'):
+        value = os.environ.get(var, '')
+        if value and value.lower() != 'none':
+            return f'{var}={value}'
+    return ''
+
+
 def _launch_token() -> str:
-    """Identifies ONE launch of the ranks of this node: they are children of the same launcher process (the
-    self-launcher of np_modeling_amd/launch.py, ``torch.distributed.run``'s agent, a shell), so its pid plus its start
-    time (field 22 of /proc/<pid>/stat; pids are recycled, start times are not) plus the agent's restart count is the
-    same for every rank of the launch and different from every other launch.  ``NPM_LAUNCH_TOKEN`` overrides it for
-    launchers whose ranks are not siblings."""
+    """Identifies ONE launch of the ranks of a job, so that a rendezvous file left behind by another launch (a crashed job at a
+    reused path) is never taken for this launch's.  In order:
+
+    * ``NPM_LAUNCH_TOKEN`` -- the self-launcher (np_modeling_amd/launch.py) exports a fresh random one per launch; any other
+      launcher may set its own;
+    * an explicitly named ``NPM_RENDEZVOUS_FILE`` with a job id in the environment (torch.distributed.run's run id, the SLURM
+      job id): job id + ``MASTER_ADDR:MASTER_PORT`` + the agent's restart count -- the same for every rank of the job whoever
+      its parent process is, different for a later job;
+    * an explicitly named file WITHOUT either, shared by ranks that are not all on this node (``WORLD_SIZE != LOCAL_WORLD_SIZE``):
+      an error -- nothing in the environment tells this launch from an earlier one with the same address (round 4 used the
+      address alone: a stale file then passed for a fresh one and ranks other than 0 could hand a dead id to ncclCommInitRank);
+    * otherwise the ranks of a node are children of one launcher process (torch.distributed.run's agent, a shell): its pid
+      plus its start time (field 22 of /proc/<pid>/stat; pids are recycled, start times are not) plus the restart count."""
     explicit = os.environ.get('NPM_LAUNCH_TOKEN')
     if explicit:
         return explicit
+    restart = os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')
     if os.environ.get('NPM_RENDEZVOUS_FILE'):
-        # An explicitly named file may be shared by ranks that are NOT siblings (a second node on a shared file system,
-        # ranks started from separate shells): the token must not depend on the parent process.  The rendezvous address
-        # every rank of a job agrees on takes its place; a file left at the same name by an EARLIER job with the same
-        # address is not told apart by this token -- set NPM_LAUNCH_TOKEN to a per-job value where that can happen.
-        return (f'explicit-{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}-'
-                f'{os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")}')
+        job = _job_id()
+        if job:
+            return f'{job}-{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}-{restart}'
+        world, local_world = os.environ.get('WORLD_SIZE', '1'), os.environ.get('LOCAL_WORLD_SIZE')
+        if local_world and local_world != world:
+            raise _C.NpmError('NPM_RENDEZVOUS_FILE is shared by ranks that are not children of one launcher (WORLD_SIZE='
+                              f'{world}, LOCAL_WORLD_SIZE={local_world}) and nothing identifies this launch: set NPM_LAUNCH_TOKEN '
+                              'to a value that is new for every job (or run under a launcher that exports TORCHELASTIC_RUN_ID '
+                              'or SLURM_JOB_ID); MASTER_ADDR:MASTER_PORT alone cannot tell a stale file from a fresh one')
     ppid = os.getppid()
     try:
         with open(f'/proc/{ppid}/stat') as f:
             started = f.read().rsplit(')', 1)[1].split()[19]
     except (OSError, IndexError):
         started = '0'
-    return f'{ppid}-{started}-{os.environ.get("TORCHELASTIC_RESTART_COUNT", "0")}'
+    return f'{ppid}-{started}-{restart}'
 
 
 def _private_dir() -> str:
@@ -210,9 +232,9 @@ def _exchange_unique_id(rank: int, world_size: int, timeout: float = 300.0) -> b
     if local_world and int(local_world) != world_size and not os.environ.get('NPM_RENDEZVOUS_FILE'):
         raise _C.NpmError(f'WORLD_SIZE={world_size} but LOCAL_WORLD_SIZE={local_world}: the RCCL id travels through a '
                           'file of ONE node (SURVEY.md 8e: the 8 GPUs of a node); for several nodes put '
-                          'NPM_RENDEZVOUS_FILE on a file system all of them share (and give every rank the same '
-                          'MASTER_ADDR / MASTER_PORT, or one NPM_LAUNCH_TOKEN per job: the file carries that token and ranks '
-                          'accept only a file with theirs)')
+                          'NPM_RENDEZVOUS_FILE on a file system all of them share and give every rank the same '
+                          'NPM_LAUNCH_TOKEN, new for every job (or a TORCHELASTIC_RUN_ID / SLURM_JOB_ID): the file carries '
+                          'that token and ranks accept only a file with theirs')
     path = rendezvous_path()
     if rank == 0:
         uid = RcclCommunicator.new_unique_id()
@@ -241,8 +263,7 @@ def _exchange_unique_id(rank: int, world_size: int, timeout: float = 300.0) -> b
             what = 'only a file of another launch' if seen_foreign else 'no file'
             raise _C.NpmError(f'rank {rank}: no RCCL id from rank 0 at {path} after {timeout:.0f} s ({what}); '
                               f'launch token {_launch_token()!r}. Ranks must be children of one launcher process on one '
-                              'node, or share an explicit NPM_RENDEZVOUS_FILE together with the same MASTER_ADDR / MASTER_PORT '
-                              '(or the same NPM_LAUNCH_TOKEN)')
+                              'node, or share an explicit NPM_RENDEZVOUS_FILE together with the same NPM_LAUNCH_TOKEN (or job id)')
         time.sleep(0.01)
 
 
@@ -262,7 +283,7 @@ def init(reduce: str = 'avg') -> Communicator:
         # one rank of several on this node: die with the launcher, and run on the CPUs of the GPU's own NUMA node --
         # both before anything touches the device (the driver's threads inherit the mask)
         from np_modeling_amd import launch
-        launch.die_with_parent()
+        launch.die_with_launcher()
         if _C._LIB is None:
             PLACEMENT = launch.bind_to_gpu_cpus(int(os.environ.get('LOCAL_RANK', str(rank))))
         else:

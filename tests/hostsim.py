@@ -53,7 +53,7 @@ class HostSim:
 
     # ---- runtime ---------------------------------------------------------------------
     def npm_abi_version(self):
-        return 1
+        return 2
 
     def npm_last_error(self):
         return self._err

@@ -58,7 +58,7 @@ def test_struct_layouts_match_header(built):
             decl = decl.strip()
             if not decl:
                 continue
-            decl = re.sub(r'^(const\s+)?(float|int32_t|int64_t)\s*\*?', '', decl)
+            decl = re.sub(r'^(const\s+)?(float|int32_t|int64_t|uint8_t)\s*\*?', '', decl)
             out += [n.strip().lstrip('*') for n in decl.split(',')]
         return out
 
@@ -70,8 +70,11 @@ def test_struct_layouts_match_header(built):
     prog = ('#include <stdio.h>\n#include <stddef.h>\n#include "npm_hip.h"\n#include "npm_comm.h"\n'
             'int main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(npm_gemm), offsetof(npm_gemm, alpha), '
             'offsetof(npm_gemm, split_k), sizeof(npm_conv2d), offsetof(npm_conv2d, relu));'
-            'printf("%zu %zu %zu\\n", sizeof(npm_comm_exchange_stats), offsetof(npm_comm_exchange_stats, waits), '
-            'offsetof(npm_comm_exchange_stats, exposed_ms));return 0;}\n')
+            'printf("%zu %zu %zu %zu %zu\\n", sizeof(npm_comm_exchange_stats), offsetof(npm_comm_exchange_stats, waits), '
+            'offsetof(npm_comm_exchange_stats, exposed_ms), offsetof(npm_comm_exchange_stats, last_allreduce_ms), '
+            'offsetof(npm_comm_exchange_stats, dropped));'
+            'printf("%zu %zu %zu %zu %zu %d\\n", sizeof(npm_mha_core), offsetof(npm_mha_core, mask), offsetof(npm_mha_core, dctx), '
+            'offsetof(npm_mha_core, tile_summary), offsetof(npm_mha_core, summary_all_offset), NPM_ABI_VERSION);return 0;}\n')
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, 'abi.c')
         open(src, 'w').write(prog)
@@ -81,14 +84,19 @@ def test_struct_layouts_match_header(built):
     want = [ctypes.sizeof(_C.npm_gemm), _C.npm_gemm.alpha.offset, _C.npm_gemm.split_k.offset,
             ctypes.sizeof(_C.npm_conv2d), _C.npm_conv2d.relu.offset,
             ctypes.sizeof(_C.npm_comm_exchange_stats), _C.npm_comm_exchange_stats.waits.offset,
-            _C.npm_comm_exchange_stats.exposed_ms.offset]
+            _C.npm_comm_exchange_stats.exposed_ms.offset, _C.npm_comm_exchange_stats.last_allreduce_ms.offset,
+            _C.npm_comm_exchange_stats.dropped.offset,
+            ctypes.sizeof(_C.npm_mha_core), _C.npm_mha_core.mask.offset, _C.npm_mha_core.dctx.offset,
+            _C.npm_mha_core.tile_summary.offset, _C.npm_mha_core.summary_all_offset.offset, 2]
     assert got == want
+    # every struct of the header that grew since version 1 is covered above; the ctypes mirror of npm_mha_core field by field
+    assert c_fields('npm_mha_core') == [f[0] for f in _C.npm_mha_core._fields_]
 
 
 def test_abi_version_and_no_device_behaviour(built):
     _C = built
     lib = _C.load_library()
-    assert lib.npm_abi_version() == 1
+    assert lib.npm_abi_version() == 2
     count = ctypes.c_int(-1)
     lib.npm_device_count(ctypes.byref(count))
     if count.value > 0:
@@ -130,29 +138,20 @@ def test_no_kernel_spills_vector_registers(built):
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import kernel_meta
     lib_dir = os.path.dirname(built.LIB_PATH)
-    # The masked forward at head size 128 sits at the 128-register budget of eight waves per block; the compiler parks
-    # four to six values of the tile-summary setup in scratch.  That is accepted ONLY while every scratch access stays
-    # outside the key-tile loop (nesting depth 2: blocks of the query-tile pair loop at depth 1 run once or twice per
-    # block) -- checked on the disassembly below.
-    OUTSIDE_THE_TILE_LOOP = ('mha_fwd8_kernel<128, true, true>', 'mha_fwd8_kernel<128, true, false>')
-    seen, spilled = 0, []
+    seen = 0
     for obj in sorted(glob.glob(os.path.join(lib_dir, 'npm_*.o'))):
         for name, meta in kernel_meta.kernel_metadata(obj).items():
             if not any(tag in name for tag in ('mha_', 'sgemm_', 'conv_')):
                 continue
             seen += 1
-            if any(tag in name for tag in OUTSIDE_THE_TILE_LOOP):
-                spilled.append(name)
-                assert meta['.vgpr_spill_count'] <= 8 and meta['.private_segment_fixed_size'] <= 32, (name, meta)
-                continue
+            # no exceptions (rounds 3-4 excused the masked forward at head size 128 for 6 registers of its tile-summary setup;
+            # round 5 recomputes the lane index per query tile instead of keeping what derives from it alive across the loop)
             assert meta['.vgpr_spill_count'] == 0 and meta['.private_segment_fixed_size'] == 0, (name, meta)
             if 'mha_bwd_kernel<128' in name:
                 assert meta['.group_segment_fixed_size'] <= 160 * 1024
     assert seen >= 40
     import waitcnt_check
-    depth = waitcnt_check.scratch_depth(waitcnt_check.assembly('npm_attn.hip'))
-    assert set(depth) <= {n.replace('(anonymous namespace)::', '') for n in spilled}, (depth, spilled)      # nobody else touches scratch
-    assert all(d <= 1 for d in depth.values()), depth
+    assert waitcnt_check.scratch_depth(waitcnt_check.assembly('npm_attn.hip')) == {}      # no scratch instruction in any attention kernel
     # the instance of round 2's spill no longer exists: saved scores carry the mask (csrc/npm_attn.hip launch_bwd)
     attn = kernel_meta.kernel_metadata(os.path.join(lib_dir, 'npm_attn.o'))
     assert not any('mha_bwd_kernel<128, true, true' in name for name in attn)

@@ -271,7 +271,8 @@ def test_data_parallel_equivalence_gloo(world):
 def _clean_env(**extra):
     env = dict(os.environ, OMP_NUM_THREADS='1')
     env.update(NPM_NO_AUTOBUILD='1', **extra) if 'NPM_NO_AUTOBUILD' not in extra else env.update(extra)
-    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'NPM_RENDEZVOUS_FILE'):
+    for key in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'LOCAL_WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT', 'NPM_RENDEZVOUS_FILE', 'NPM_LAUNCH_TOKEN',
+                'NPM_LAUNCHER_PID', 'TORCHELASTIC_RUN_ID', 'SLURM_JOB_ID'):
         env.pop(key, None)
     return env
 
@@ -692,15 +693,98 @@ def test_gpu_local_cpus_from_a_fake_sysfs(tmp_path, monkeypatch):
 
 def test_explicit_rendezvous_file_shared_by_ranks_of_different_parents(tmp_path):
     """Two ranks started by DIFFERENT parent processes (two shells, two nodes on a shared file system) that share an explicit
-    NPM_RENDEZVOUS_FILE and the same MASTER_ADDR / MASTER_PORT: the launch token of an explicit file does not depend on the
-    parent, so rank 1 accepts rank 0's id (round-3 advisor: it used to time out after 300 s)."""
-    env = dict(_clean_env(), NPM_RENDEZVOUS_FILE=str(tmp_path / 'shared_id'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29517',
-               WORLD_SIZE='2', LOCAL_WORLD_SIZE='1')
+    NPM_RENDEZVOUS_FILE: with one NPM_LAUNCH_TOKEN for the job (or a job id from the launcher) rank 1 accepts rank 0's id whoever
+    its parent is; WITHOUT one the ranks fail at once with the reason (round-4 advisor: MASTER_ADDR:MASTER_PORT alone stood in
+    for the token, and a stale file of an earlier job at the same address passed for a fresh one)."""
+    base = dict(_clean_env(), NPM_RENDEZVOUS_FILE=str(tmp_path / 'shared_id'), MASTER_ADDR='127.0.0.1', MASTER_PORT='29517',
+                WORLD_SIZE='2', LOCAL_WORLD_SIZE='1')
     worker = os.path.join(ROOT, 'tests', 'uid_worker.py')
     # each rank is the child of its own intermediate process
     hop = 'import subprocess, sys; sys.exit(subprocess.call([sys.executable, sys.argv[1]]))'
-    procs = [subprocess.Popen([sys.executable, '-c', hop, worker], env=dict(env, RANK=str(r), LOCAL_RANK='0'), cwd=ROOT,
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (1, 0)]
-    outs = [p.communicate(timeout=120)[0] for p in procs]
-    assert [p.returncode for p in procs] == [0, 0], outs
-    assert 'rank 1/2: id ok' in outs[0] and 'rank 0/2: id ok' in outs[1]
+
+    def run(env):
+        procs = [subprocess.Popen([sys.executable, '-c', hop, worker], env=dict(env, RANK=str(r), LOCAL_RANK='0'), cwd=ROOT,
+                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in (1, 0)]
+        outs = [p.communicate(timeout=120)[0] for p in procs]
+        return [p.returncode for p in procs], outs
+
+    for extra in (dict(NPM_LAUNCH_TOKEN='job-4711'), dict(TORCHELASTIC_RUN_ID='run-17'), dict(SLURM_JOB_ID='990')):
+        codes, outs = run(dict(base, **extra))
+        assert codes == [0, 0], outs
+        assert 'rank 1/2: id ok' in outs[0] and 'rank 0/2: id ok' in outs[1]
+    codes, outs = run(dict(base, TORCHELASTIC_RUN_ID='none'))                 # torch.distributed.run's default: not a job id
+    assert all(c != 0 for c in codes), outs
+    assert all('NPM_LAUNCH_TOKEN' in o for o in outs), outs
+
+
+def test_stale_rendezvous_file_with_the_same_address_is_rejected(tmp_path, monkeypatch):
+    """A crashed job leaves its file at a reused NPM_RENDEZVOUS_FILE; the next job has the SAME MASTER_ADDR / MASTER_PORT.  Its
+    ranks must skip that file whichever way they were launched: self-launched ranks carry a fresh random token per launch,
+    externally launched ranks of one node their launcher's pid + start time, ranks with a job id that id."""
+    from np_modeling_amd import _C, launch, parallel
+    uid_old, uid_new = bytes(range(128)), bytes(reversed(range(128)))
+    path = str(tmp_path / 'reused_id')
+    for var in ('NPM_LAUNCH_TOKEN', 'TORCHELASTIC_RUN_ID', 'SLURM_JOB_ID', 'LOCAL_WORLD_SIZE'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv('NPM_RENDEZVOUS_FILE', path)
+    monkeypatch.setenv('MASTER_ADDR', '127.0.0.1')
+    monkeypatch.setenv('MASTER_PORT', '29600')
+    monkeypatch.setenv('WORLD_SIZE', '2')
+
+    # (1) two launches of the self-launcher: different tokens although everything else in the environment is equal
+    env_a = launch.rank_environment(0, 2, path, base=dict(os.environ))
+    env_b = launch.rank_environment(0, 2, path, base=dict(os.environ))
+    assert env_a['NPM_LAUNCH_TOKEN'] != env_b['NPM_LAUNCH_TOKEN'] and env_a['NPM_LAUNCHER_PID'] == str(os.getpid())
+    tok = launch.new_launch_token()
+    assert [launch.rank_environment(r, 2, path, base={}, token=tok)['NPM_LAUNCH_TOKEN'] for r in (0, 1)] == [tok, tok]
+    monkeypatch.setenv('NPM_LAUNCH_TOKEN', env_a['NPM_LAUNCH_TOKEN'])
+    monkeypatch.setattr(parallel.RcclCommunicator, 'new_unique_id', staticmethod(lambda: uid_old))
+    assert parallel._exchange_unique_id(0, 2) == uid_old                      # job A writes its id and crashes
+    monkeypatch.setenv('NPM_LAUNCH_TOKEN', env_b['NPM_LAUNCH_TOKEN'])
+    with pytest.raises(_C.NpmError, match='only a file of another launch'):
+        parallel._exchange_unique_id(1, 2, timeout=0.2)                       # job B's rank 1 races its rank 0: skips the stale file
+    monkeypatch.setattr(parallel.RcclCommunicator, 'new_unique_id', staticmethod(lambda: uid_new))
+    assert parallel._exchange_unique_id(0, 2) == uid_new
+    assert parallel._exchange_unique_id(1, 2, timeout=5) == uid_new
+
+    # (2) an external launcher on one node, no token, no job id: the parent's pid + start time.  A file packed under the
+    # round-4 token (the address alone) -- or under any other parent -- is not accepted
+    monkeypatch.delenv('NPM_LAUNCH_TOKEN')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '2')
+    token = parallel._launch_token()
+    assert token.startswith(f'{os.getppid()}-') and '29600' not in token
+    stale = parallel._ID_MAGIC + (33).to_bytes(2, 'little') + b'explicit-127.0.0.1:29600-0'.ljust(33, b' ') + uid_old
+    with open(path, 'wb') as f:
+        f.write(stale)
+    with pytest.raises(_C.NpmError, match='only a file of another launch'):
+        parallel._exchange_unique_id(1, 2, timeout=0.2)
+
+    # (3) a job id: equal for the ranks of a job, different for the next job at the same address
+    monkeypatch.setenv('SLURM_JOB_ID', '1001')
+    assert parallel._exchange_unique_id(0, 2) == uid_new
+    monkeypatch.setenv('SLURM_JOB_ID', '1002')
+    with pytest.raises(_C.NpmError, match='only a file of another launch'):
+        parallel._exchange_unique_id(1, 2, timeout=0.2)
+
+    # (4) several nodes (or parents) and nothing that identifies the launch: an error at once, not a guess
+    monkeypatch.delenv('SLURM_JOB_ID')
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '1')
+    with pytest.raises(_C.NpmError, match='NPM_LAUNCH_TOKEN'):
+        parallel._exchange_unique_id(1, 2, timeout=0.2)
+
+
+def test_rank_dies_with_its_launcher_only(monkeypatch):
+    """PR_SET_PDEATHSIG is armed by a rank only when this package's launcher is its parent (NPM_LAUNCHER_PID == getppid()); a rank
+    started from a shell or wrapper that exits on purpose is left alone; NPM_DIE_WITH_PARENT=0 switches it off."""
+    from np_modeling_amd import launch
+    calls = []
+    monkeypatch.setattr(launch, 'die_with_parent', lambda: calls.append(1) or True)
+    monkeypatch.delenv('NPM_LAUNCHER_PID', raising=False)
+    monkeypatch.delenv('NPM_DIE_WITH_PARENT', raising=False)
+    assert launch.die_with_launcher() is False and not calls                  # an external launcher's rank
+    monkeypatch.setenv('NPM_LAUNCHER_PID', str(os.getppid() + 1))
+    assert launch.die_with_launcher() is False and not calls                  # the launcher is not our parent (a wrapper in between)
+    monkeypatch.setenv('NPM_LAUNCHER_PID', str(os.getppid()))
+    assert launch.die_with_launcher() is True and calls == [1]
+    monkeypatch.setenv('NPM_DIE_WITH_PARENT', '0')
+    assert launch.die_with_launcher() is False and calls == [1]
