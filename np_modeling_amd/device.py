@@ -37,7 +37,7 @@ def _prod(shape: Sequence[int]) -> int:
 class _Buffer:
     """Owns one pool block; returns it to the stream-ordered pool when unreferenced."""
 
-    __slots__ = ('ptr', 'nbytes')
+    __slots__ = ('ptr', 'nbytes', '__weakref__')
 
     def __init__(self, nbytes: int):
         lib = _C.lib()
@@ -218,6 +218,10 @@ class DeviceArray:
         elif not isinstance(other, DeviceArray) or other.size != self.size:
             host = np.asarray(other, dtype=np.float32)
             other = from_host(np.broadcast_to(host, self.shape))
+        queue = UpdateQueue.active
+        if queue is not None:                       # inside coalesced_updates(): launched, merged with its neighbours, at the end
+            queue.axpy(self, other, float(alpha))
+            return self
         _C.check(_C.lib().npm_axpy(self.ptr, other.ptr, float(alpha), self.size), 'npm_axpy')
         return self
 
@@ -313,6 +317,167 @@ ArrayLike = Union[DeviceArray, np.ndarray, Sequence]
 
 
 # ---- constructors ------------------------------------------------------------------------
+# ---- parameters back to back, updates in one launch ------------------------------------------------------------------
+COALESCE_UPDATES = os.environ.get('NPM_COALESCE_UPDATES', '1') != '0'   # A/B switch: 0 = one optimizer launch per parameter (rounds 1-4)
+_ALIGN = 4                                                              # floats: 16-byte aligned slices (GEMM / DMA operands)
+
+
+class _LayerRef:
+    """Weak reference to a layer that survives ``copy.deepcopy`` of the structure holding it by pointing at the COPY of
+    the layer (through the deepcopy memo).  A ParamArena is an attribute of the layer whose parameters it lists: strong
+    references would make every layer a reference cycle, and its device memory would wait for the cycle collector."""
+    __slots__ = ('_ref',)
+
+    def __init__(self, obj):
+        import weakref
+        self._ref = weakref.ref(obj)
+
+    def __call__(self):
+        return self._ref()
+
+    def __deepcopy__(self, memo):
+        import copy
+        target = self._ref()
+        return _LayerRef(copy.deepcopy(target, memo)) if target is not None else self
+
+
+class ParamArena:
+    """The parameters of one layer (a composite's sub-layers included) back to back in ONE device buffer, in the order
+    their gradients are produced by ``backward`` -- so that the flat gradient bucket of parallel.GradScope mirrors it
+    slot for slot and ``parameter -= lr * gradient`` (reference optimizer.py:26-33; Adam: :53-67) is ONE launch over the
+    whole range instead of one per parameter.
+
+    ``segments`` is a list of lists of ``(layer, attribute)``; the parameters of one segment stay gap-free (the packed
+    wq / wk / wv of MultiHeadAttention must remain adjacent), every segment starts 16-byte aligned.  Building the arena
+    COPIES the current values and rebinds the attributes to views of it, so it is built where no outside alias of a
+    parameter can exist yet (inside ``initialize``) or where one would be re-taken anyway (end of a composite's first
+    forward; the reference's tests take their aliases after the first call).  A parameter that is rebound later
+    (weight binders assign arrays into the private attributes, reference layers/utils.py:52-88) simply leaves the
+    arena: ``offset_of`` returns None for it and it takes the per-parameter path again."""
+
+    def __init__(self, segments):
+        self.entries = []                            # [layer, attribute, offset, size]
+        offset = 0
+        for segment in segments:
+            offset = (offset + _ALIGN - 1) // _ALIGN * _ALIGN
+            for obj, attribute in segment:
+                value = obj._param(attribute)
+                self.entries.append([_LayerRef(obj), attribute, offset, value.size])
+                offset += value.size
+        self.size = (offset + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.flat = zeros([max(self.size, 1)])       # zeros: the alignment gaps are updated along with their neighbours
+        for ref, attribute, off, n in self.entries:
+            obj = ref()
+            old = obj._param(attribute)
+            view = self.flat.flat_view(off, old.shape)
+            if n:
+                _C.check(_C.lib().npm_d2d(view.ptr, old.ptr, 4 * n), 'npm_d2d')
+            setattr(obj, attribute, view)
+
+    def offset_of(self, obj, attribute: str, size: int) -> Optional[int]:
+        """Where (in floats) ``obj.attribute`` starts inside the arena if ``size`` elements from there are still what
+        the attribute(s) hold -- None once a binder has rebound it."""
+        for ref, a, off, n in self.entries:
+            if a == attribute and ref() is obj:
+                value = getattr(obj, attribute)
+                if isinstance(value, DeviceArray) and value.ptr == self.flat.ptr + 4 * off and value._buf is self.flat._buf \
+                        and off + size <= self.size:
+                    return off
+                return None
+        return None
+
+    def live(self) -> int:
+        """How many of the parameters are still where the arena put them."""
+        return sum(ref() is not None and self.offset_of(ref(), a, n) == off for ref, a, off, n in self.entries)
+
+
+class _Pending:
+    """One queued update: ``n`` elements at ``var`` and ``grad`` (byte addresses inside the blocks ``var_buf`` / ``grad_buf``),
+    side arrays ``extra`` = ((byte address, bytes per element), ...) and ``key`` = everything two updates must agree on to
+    be one launch (kind, step size, Adam's hyper-parameters and step number)."""
+    __slots__ = ('var', 'grad', 'n', 'key', 'var_buf', 'grad_buf', 'extra')
+
+    def __init__(self, var, grad, n, key, var_buf, grad_buf, extra=()):
+        self.var, self.grad, self.n, self.key, self.var_buf, self.grad_buf, self.extra = var, grad, n, key, var_buf, grad_buf, extra
+
+    def continued_by(self, other: '_Pending') -> bool:
+        """``other`` starts where this ends -- or up to 3 floats later, the alignment padding between two slices of an
+        arena, which the blocks own on every side and which may be updated along (nothing reads it) -- on the parameter
+        side, the gradient side and every side array alike."""
+        gap = other.var - (self.var + 4 * self.n)
+        if gap < 0 or gap > 4 * (_ALIGN - 1) or gap % 4 or self.key != other.key:
+            return False
+        if self.var_buf is not other.var_buf or self.grad_buf is not other.grad_buf or len(self.extra) != len(other.extra):
+            return False
+        if other.grad - (self.grad + 4 * self.n) != gap:
+            return False
+        return all(width == w2 and ptr2 - (ptr + width * self.n) == gap // 4 * width
+                   for (ptr, width), (ptr2, w2) in zip(self.extra, other.extra))
+
+
+class UpdateQueue:
+    """Parameter updates issued inside ``coalesced_updates()`` are collected instead of launched; on exit, updates whose
+    parameters AND gradients (AND Adam moments) are neighbours in memory -- a ParamArena and the gradient bucket that
+    mirrors it -- run as one launch over the joined range.  The optimizer is not involved: the reference's unchanged
+    ``SGDOptimizer.update_variable`` (``variable -= lr * gradient``, optimizer.py:32) reaches ``DeviceArray._axpy``
+    exactly as before, once per ``Optimizer.update(obj, attribute, grad)``, with its ``id(obj).attribute`` keying.
+    Elementwise updates do not care where a range is cut: results are bit-identical to the per-parameter launches."""
+
+    active: Optional['UpdateQueue'] = None
+
+    def __init__(self):
+        self._pending = []
+        self.launches = 0        # kernels launched by run()
+        self.updates = 0         # updates they stand for
+
+    def axpy(self, var: 'DeviceArray', grad: 'DeviceArray', alpha: float) -> None:
+        self._pending.append(_Pending(var.ptr, grad.ptr, var.size, ('axpy', alpha), var._buf, grad._buf))
+
+    def adam(self, var: 'DeviceArray', grad: 'DeviceArray', first_ptr: int, second_ptr: int, hyper: tuple, owner) -> None:
+        """``hyper`` = (lr, beta1, beta2, epsilon, step); ``owner`` keeps the moment buffers alive until run()."""
+        self._pending.append(_Pending(var.ptr, grad.ptr, var.size, ('adam',) + tuple(hyper), var._buf, grad._buf,
+                                      ((first_ptr, 8), (second_ptr, 8))))
+        self._keep = getattr(self, '_keep', [])
+        self._keep.append(owner)
+
+    def run(self) -> None:
+        lib = _C.lib()
+        pending, self._pending = sorted(self._pending, key=lambda u: (u.key[0], u.var)), []
+        self.updates += len(pending)
+        run: Optional[_Pending] = None
+        for item in pending + [None]:
+            if run is not None and item is not None and run.continued_by(item):
+                run.n = (item.var - run.var) // 4 + item.n
+                continue
+            if run is not None and run.n:
+                if run.key[0] == 'axpy':
+                    _C.check(lib.npm_axpy(run.var, run.grad, run.key[1], run.n), 'npm_axpy')
+                else:
+                    lr, b1, b2, eps, step = run.key[1:]
+                    _C.check(lib.npm_adam_step(run.var, run.grad, run.extra[0][0], run.extra[1][0], run.n, lr, b1, b2, eps,
+                                               step), 'npm_adam_step')
+                self.launches += 1
+            run = item
+        self._keep = []
+
+
+class coalesced_updates:
+    """``with coalesced_updates():`` -- see UpdateQueue.  Nests: an inner context joins the outer one."""
+
+    def __enter__(self) -> UpdateQueue:
+        self._mine = UpdateQueue.active is None and COALESCE_UPDATES
+        if self._mine:
+            UpdateQueue.active = UpdateQueue()
+        return UpdateQueue.active
+
+    def __exit__(self, exc_type, exc, tb) -> bool:
+        if self._mine:
+            queue, UpdateQueue.active = UpdateQueue.active, None
+            if exc_type is None:
+                queue.run()
+        return False
+
+
 def empty(shape: Sequence[int]) -> DeviceArray:
     return DeviceArray(shape)
 

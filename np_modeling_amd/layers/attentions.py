@@ -88,6 +88,8 @@ class MultiHeadAttention(layer.StatefulLayer):
             self._bq, self._bk, self._bv = (D.as_device(a) for a in bias_draws)
         self._wo = D.as_device(wo)
         self._bo = D.as_device(bo)
+        # one arena in the order backward produces the gradients (dbo, dwo, the in-projection weights, their biases)
+        self._pack_parameters(self._segments())
 
     def _params_adjacent(self) -> bool:
         """wq/wk/wv (and bq/bk/bv) still back to back in memory?  Checked at EVERY use: parameters may be
@@ -106,6 +108,11 @@ class MultiHeadAttention(layer.StatefulLayer):
 
     def _numel(self) -> int:
         return sum(self._param(p).size for p in _PARAMS) + 4 * len(_PARAMS)
+
+    def _segments(self):
+        """Parameters in the order ``_backward_impl`` produces their gradients (device.ParamArena segments)."""
+        return [[(self, '_bo')], [(self, '_wo')], [(self, '_wq'), (self, '_wk'), (self, '_wv')],
+                [(self, '_bq'), (self, '_bk'), (self, '_bv')]]
 
     # -- forward -------------------------------------------------------------------------
     def forward(self, query, key=None, value=None, mask=None):
@@ -186,7 +193,7 @@ class MultiHeadAttention(layer.StatefulLayer):
 
     # -- backward --------------------------------------------------------------------------
     def backward(self, dy, optimizer_):
-        with parallel.grad_scope(self._numel()) as scope:
+        with parallel.grad_scope(self._numel(), self._arena) as scope:
             return self._backward_impl(D.as_device(dy), optimizer_, scope)
 
     def _backward_impl(self, dy, optimizer_, scope, *, sum_inputs: bool = False, sum_kv: bool = False,
@@ -206,8 +213,8 @@ class MultiHeadAttention(layer.StatefulLayer):
 
         # output projection (attentions.py:129-136)
         # dbo = sum over (batch, position) of dy: taken from the dy tiles of the weight-gradient GEMM
-        dbo = scope.take([f])
-        dwo = scope.take(wo.shape)
+        dbo = scope.take([f], owner=(self, '_bo'))
+        dwo = scope.take(wo.shape, owner=(self, '_wo'))
         D.gemm(f, h * dv, m_q, Mat(dy, f), Mat(ctx, h * dv), Mat(dwo, h * dv), trans_a=True, asum_out=dbo)   # dy^T ctx
         dctx = D.empty([b, sq, h, dv])
         D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))                    # dy wo
@@ -217,15 +224,15 @@ class MultiHeadAttention(layer.StatefulLayer):
         # dbq/dbk/dbv = sum over (batch, position) of dq/dk/dv (attentions.py:186-188): taken from the dq/dk/dv
         # tiles of the in-projection weight-gradient GEMMs below
         if packed:      # gradients of the packed parameters and of q/k/v live in packed buffers too
-            dw_all, db_all = scope.take([3, h, dk, f]), scope.take([3, h, dk])
+            dw_all, db_all = scope.take([3, h, dk, f], owner=(self, '_wq')), scope.take([3, h, dk], owner=(self, '_bq'))
             dwq, dwk, dwv = (dw_all.flat_view(i * h * dk * f, [h, dk, f]) for i in range(3))
             dbq, dbk, dbv = (db_all.flat_view(i * h * dk, [h, dk]) for i in range(3))
             dqkv = D.empty([b, sq, 3, h, dk])
             dq, dk_, dv_ = dqkv, dqkv.flat_view(f, [dqkv.size - f]), dqkv.flat_view(2 * f, [dqkv.size - 2 * f])
             gq = gk = gv = 3 * f
         else:
-            dwq, dwk, dwv = scope.take(wq.shape), scope.take(wk.shape), scope.take(wv.shape)
-            dbq, dbk, dbv = scope.take([h, dk]), scope.take([h, dk]), scope.take([h, dv])
+            dwq, dwk, dwv = (scope.take(w_.shape, owner=(self, a_)) for w_, a_ in ((wq, '_wq'), (wk, '_wk'), (wv, '_wv')))
+            dbq, dbk, dbv = (scope.take([h, d_], owner=(self, a_)) for d_, a_ in ((dk, '_bq'), (dk, '_bk'), (dv, '_bv')))
             dq, dk_, dv_ = D.empty([b, sq, h, dk]), D.empty([b, skv, h, dk]), D.empty([b, skv, h, dv])
             gq, gk, gv = h * dk, h * dk, h * dv
         if self._core:

@@ -36,6 +36,7 @@ class Conv2D(layer.StatefulLayer):
         k = self._kernel_size
         self._w = self._new_param([k, k, self._input_channels, self._output_channels])
         self._b = self._new_param([self._output_channels])
+        self._pack_parameters([[(self, '_b')], [(self, '_w')]])
         self._activation.initialize()
 
     def _fused_relu(self) -> bool:
@@ -69,9 +70,9 @@ class Conv2D(layer.StatefulLayer):
         assert dy.shape[3] == self._output_channels
         n, h, wd, c0 = x.shape
         k, c1 = self._kernel_size, self._output_channels
-        with parallel.grad_scope(w.size + c1 + 8) as scope:
-            db = scope.take([c1])
-            dw = scope.take(w.shape)
+        with parallel.grad_scope(w.size + c1 + 8, self._arena) as scope:
+            db = scope.take([c1], owner=(self, '_b'))
+            dw = scope.take(w.shape, owner=(self, '_w'))
             flops = 2.0 * n * h * wd * c1 * k * k * c0
             if self._fused_relu():
                 # relu' (activations.py:19), db and dw (conv.py:54-56) in one call: the mask is applied where the

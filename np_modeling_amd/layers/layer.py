@@ -67,6 +67,15 @@ class Layer(abc.ABC):
         return self.forward(*inputs, **kwargs)
 
     # ---- shared by the device layers --------------------------------------------------------------------
+    _arena = None           # device.ParamArena of this layer's parameters (built by layers that have several)
+
+    def _pack_parameters(self, segments) -> None:
+        """Move the parameters named by ``segments`` (lists of (layer, attribute), in the order ``backward`` produces their
+        gradients) into one device.ParamArena, so that the deferred updates of a backward are one launch.  Called where
+        no outside alias of a parameter can be stale afterwards: from ``initialize`` or at the end of the first forward."""
+        if D.COALESCE_UPDATES:
+            self._arena = D.ParamArena(segments)
+
     def _param(self, attribute: str) -> D.DeviceArray:
         """Current value of a parameter as a DeviceArray.  Tests and weight binders assign arbitrary array-likes
         into the private attributes (reference layers/utils.py:52-88); such a value moves to the device on first

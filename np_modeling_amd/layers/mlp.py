@@ -26,6 +26,7 @@ class Linear(layer.StatefulLayer):
         # draw order w then b (mlp.py:18-19)
         self._w = self._new_param([self._input_units, self._output_units])
         self._b = self._new_param([self._output_units])
+        self._pack_parameters([[(self, '_b')], [(self, '_w')]])      # the order backward produces db, dw in
 
     # -- forward ---------------------------------------------------------------------
     def forward(self, x):
@@ -47,7 +48,7 @@ class Linear(layer.StatefulLayer):
 
     # -- backward --------------------------------------------------------------------
     def backward(self, dy, optimizer_):
-        with parallel.grad_scope(self._w.size + self._b.size + 8) as scope:
+        with parallel.grad_scope(self._w.size + self._b.size + 8, self._arena) as scope:
             return self._backward_impl(D.as_device(dy), optimizer_, scope)
 
     def _backward_impl(self, dy: D.DeviceArray, optimizer_, scope, *,
@@ -66,8 +67,8 @@ class Linear(layer.StatefulLayer):
         m = dy.shape[0]
         have_db = db is not None
         if not have_db:
-            db = scope.take([n])
-        dw = scope.take([k, n])
+            db = scope.take([n], owner=(self, '_b'))
+        dw = scope.take([k, n], owner=(self, '_w'))
         # x^T @ dy; the same GEMM sums its dy tiles over the batch: db = np.sum(dy, axis=0) (mlp.py:34)
         D.gemm(k, n, m, Mat(x, k), Mat(dy, n), Mat(dw, n), trans_a=True, bsum_out=None if have_db else db)
         dx = None
@@ -120,10 +121,10 @@ class Dense(layer.StatefulLayer):
 
     def backward(self, dy, optimizer_):
         lin = self._linear
-        with parallel.grad_scope(lin._w.size + lin._b.size + 8) as scope:
+        with parallel.grad_scope(lin._w.size + lin._b.size + 8, lin._arena) as scope:
             dy = D.as_device(dy)
             if self._fused_relu():           # relu' (mlp.py:74) and db (mlp.py:34) in one pass over dy
-                db = scope.take([lin._output_units])
+                db = scope.take([lin._output_units], owner=(lin, '_b'))
                 g = D.relu_bwd_colsum(self._activation._x, dy, lin._output_units, db)
                 return lin._backward_impl(g, optimizer_, scope, db=db)
             return lin._backward_impl(self._activation.backward(dy), optimizer_, scope)

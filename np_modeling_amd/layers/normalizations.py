@@ -103,6 +103,7 @@ class LayerNormalization(layer.StatefulLayer):
         self._col = x.shape[-1]
         self._gamma = self._new_param([self._col])
         self._beta = self._new_param([self._col])
+        self._pack_parameters([[(self, '_gamma')], [(self, '_beta')]])
 
     def forward(self, x):
         x = D.as_device(x)
@@ -114,7 +115,7 @@ class LayerNormalization(layer.StatefulLayer):
         return z
 
     def backward(self, dl_dz, optimizer_):
-        with parallel.grad_scope(2 * self._param('_gamma').size + 8) as scope:
+        with parallel.grad_scope(2 * self._param('_gamma').size + 8, self._arena) as scope:
             return self._backward_impl(D.as_device(dl_dz), optimizer_, scope)
 
     def _backward_impl(self, dz: D.DeviceArray, optimizer_, scope,
@@ -124,7 +125,7 @@ class LayerNormalization(layer.StatefulLayer):
         gamma = self._param('_gamma')
         d = x.shape[-1]
         assert dz.size == x.size, f'{dz.shape} vs {x.shape}'
-        dgamma, dbeta = scope.take([d]), scope.take([d])
+        dgamma, dbeta = scope.take([d], owner=(self, '_gamma')), scope.take([d], owner=(self, '_beta'))
         dx = D.layernorm_bwd(dz, x, self._mean, self._rstd, gamma, dgamma, dbeta, residual=residual)
         scope.defer(optimizer_, self, '_gamma', dgamma)
         scope.defer(optimizer_, self, '_beta', dbeta)

@@ -21,6 +21,20 @@ def _identity_dropout(*dropouts) -> bool:
     return all(d._drop_prob == 0.0 for d in dropouts)
 
 
+def _linear_segments(lin):
+    return [[(lin, '_b')], [(lin, '_w')]]              # Linear._backward_impl takes db, then dw
+
+
+def _norm_segments(norm):
+    return [[(norm, '_gamma')], [(norm, '_beta')]]
+
+
+def _block_segments(norm, body, norm_first: bool):
+    """A residual block's parameters in the order its backward produces their gradients: the norm's come after the
+    body's with pre-norm, before them with post-norm."""
+    return body + _norm_segments(norm) if norm_first else _norm_segments(norm) + body
+
+
 # A transformer layer is a chain of residual blocks around a body (attention or the feed-forward pair):
 #     pre-norm :  y = x + body(norm(drop(x)))          post-norm:  y = norm(drop(x + body(x)))
 # The two helpers below are that block and its mirror image, built from standalone device adds -- the literal
@@ -66,6 +80,20 @@ class TransformerEncoder(layer.Layer):
         norms = 2 * (self._norm1._param('_gamma').size + self._norm2._param('_gamma').size)
         return att + lin1._w.size + lin1._b.size + lin2._w.size + lin2._b.size + norms + 64
 
+    def _pack(self) -> None:
+        """After the first forward (every sub-layer has drawn its parameters, in the reference's order): all 16 parameters
+        into ONE arena, ordered as ``backward`` produces their gradients -- feed-forward block, then attention block --
+        so that gradient bucket, exchange and the deferred updates walk one range (one optimizer launch per step)."""
+        if self._arena is None:
+            pre = self._norm_first
+            ffn = _linear_segments(self._dense2) + _linear_segments(self._dense1._linear)
+            if pre:     # dense2 | dense1, norm2 | attention | norm1 -- the four flushes of _backward_fused
+                segments = ffn + _norm_segments(self._norm2) + self._self_attention._segments() + _norm_segments(self._norm1)
+            else:       # norm2, dense2 | dense1 | norm1, attention
+                segments = (_norm_segments(self._norm2) + ffn + _norm_segments(self._norm1)
+                            + self._self_attention._segments())
+            self._pack_parameters(segments)
+
     # Sub-layers initialise lazily at their first call, in call order, exactly as in the
     # reference (layer.py:33-35) -- that fixes the global-RNG draw order of the parameters.
     @staticmethod
@@ -98,6 +126,7 @@ class TransformerEncoder(layer.Layer):
         out = dense2._forward_impl(out, residual=skip)                   # ... + skip (transformer.py:53)
         if not self._norm_first:
             out = self._norm2(out)
+        self._pack()
         return out.reshape(batch, seq_len_q, features)
 
     def _feed_forward(self, x):
@@ -114,11 +143,12 @@ class TransformerEncoder(layer.Layer):
         out = _block_forward(qkv, self._norm1, self._dropout1, self._norm_first, self._self_attention)
         out = _block_forward(out.reshape(-1, features), self._norm2, self._dropout2, self._norm_first,
                              self._feed_forward)
+        self._pack()
         return out.reshape(batch, seq_len_q, features)
 
     def backward(self, dy, optimizer_):
         dy = D.as_device(dy)
-        with parallel.grad_scope(self._numel()) as scope:
+        with parallel.grad_scope(self._numel(), self._arena) as scope:
             if _identity_dropout(self._dropout1, self._dropout2) and self._dense1._fused_relu():
                 return self._backward_fused(dy, optimizer_, scope)
             return self._backward_unfused(dy, optimizer_, scope)
@@ -197,6 +227,23 @@ class TransformerDecoder(layer.Layer):
     def _fusable(self) -> bool:
         return _identity_dropout(self._dropout1, self._dropout2, self._dropout3) and self._dense1._fused_relu()
 
+    def _numel(self) -> int:
+        """Floats the gradients of one backward need (26 parameter tensors): ONE bucket for the exchange, like the
+        encoder's (round 4 opened the scope without a size: every gradient was a collective of its own at N > 1)."""
+        lin1, lin2 = self._dense1._linear, self._dense2
+        norms = sum(2 * n._param('_gamma').size for n in (self._norm1, self._norm2, self._norm3))
+        return (self._self_attention._numel() + self._cross_attention._numel() + lin1._w.size + lin1._b.size
+                + lin2._w.size + lin2._b.size + norms + 128)
+
+    def _pack(self) -> None:
+        """See TransformerEncoder._pack: feed-forward block, cross-attention block, self-attention block."""
+        if self._arena is None:
+            pre = self._norm_first
+            ffn = _linear_segments(self._dense2) + _linear_segments(self._dense1._linear)
+            ca, sa = self._cross_attention._segments(), self._self_attention._segments()
+            self._pack_parameters(_block_segments(self._norm3, ffn, pre) + _block_segments(self._norm2, ca, pre)
+                                  + _block_segments(self._norm1, sa, pre))
+
     def forward(self, q, kv):
         """Three residual blocks: self-attention, cross-attention over ``kv``, feed-forward (transformer.py:120-157).
         Without dropout the residual additions ride the producing GEMMs' epilogues, as in the encoder."""
@@ -226,6 +273,7 @@ class TransformerDecoder(layer.Layer):
         out = dense2._forward_impl(h, residual=skip)                      # ... + skip (transformer.py:152)
         if not pre:
             out = self._norm3(out)
+        self._pack()
         return out.reshape(batch, seq_len_q, features)
 
     def _forward_unfused(self, q, kv):
@@ -235,12 +283,13 @@ class TransformerDecoder(layer.Layer):
                              lambda x: self._cross_attention(x, kv))
         out = _block_forward(out.reshape(-1, features), self._norm3, self._dropout3, self._norm_first,
                              self._feed_forward)
+        self._pack()
         return out.reshape(batch, seq_len_q, features)
 
     def backward(self, dy, optimizer_):
         """Returns ``(dq, dkv)``; ``dkv`` is the cross-attention's dkey + dvalue (transformer.py:159-203)."""
         dy = D.as_device(dy)
-        with parallel.grad_scope(0) as scope:
+        with parallel.grad_scope(self._numel(), self._arena) as scope:
             if self._fusable():
                 return self._backward_fused(dy, optimizer_, scope)
             return self._backward_unfused(dy, optimizer_, scope)

@@ -384,26 +384,40 @@ class GradScope:
     composite) delegate to it.  ``take`` hands out gradient storage, ``defer`` queues an
     ``optimizer_.update``, ``flush`` starts the all-reduce of everything taken so far, and
     leaving the outermost scope waits for the exchange and applies the updates in order.
+
+    With a ``device.ParamArena`` (the layer's parameters back to back, in the order backward produces their
+    gradients) the bucket MIRRORS the arena: ``take(shape, owner=(layer, attribute))`` returns the slice at the
+    parameter's own offset, so parameter range and gradient range line up and the deferred updates run as one launch
+    (``device.coalesced_updates``).  Then there is a bucket with one rank too.
     """
 
     _active: Optional['GradScope'] = None
 
-    def __init__(self, numel_hint: int = 0):
+    def __init__(self, numel_hint: int = 0, arena: Optional['D.ParamArena'] = None):
         self._hint = int(numel_hint)
+        self._arena = arena if D.COALESCE_UPDATES else None
         self._outer: Optional[GradScope] = None
         self._bucket: Optional[D.DeviceArray] = None
-        self._offset = 0
+        self._offset = 0               # end of the sequentially carved part
+        self._spans: List[Tuple[int, int]] = []      # slices handed out and not yet flushed (start, end), any order
         self._flushed = 0
         self._started = False          # an all-reduce of this scope has been issued
         self._loose: List[D.DeviceArray] = []
         self._updates: List[Tuple[object, object, str, object]] = []
+        self.collectives = 0           # all-reduce calls this scope issued (tests: one bucket, a handful of flushes)
+        self.update_launches = None    # optimizer kernels its deferred updates ran as (None: not coalesced)
 
     # -- context management ----------------------------------------------------------
     def __enter__(self) -> 'GradScope':
         self._outer = GradScope._active
         if self._outer is None:
             GradScope._active = self
-            if communicator().active and self._hint > 0:
+            if self._arena is not None and not self._arena.live():
+                self._arena = None           # every parameter has moved on (into a composite's arena, or rebound): nothing to mirror
+            if self._arena is not None and self._arena.size > 0:
+                self._offset = self._arena.size                      # sequential takes (parameters outside the arena) go behind it
+                self._bucket = D.empty([self._arena.size + max(self._hint - self._arena.size, 0) + 64])
+            elif communicator().active and self._hint > 0:
                 self._bucket = D.empty([self._hint])
         return self
 
@@ -432,13 +446,22 @@ class GradScope:
         return self if self._outer is None else self._outer.root
 
     # -- gradient storage ------------------------------------------------------------------
-    def take(self, shape: Sequence[int]) -> D.DeviceArray:
+    def take(self, shape: Sequence[int], owner: Optional[Tuple[object, str]] = None) -> D.DeviceArray:
+        """Storage for a gradient of ``shape``.  ``owner`` = (layer, attribute) of the parameter it is the gradient of
+        (the FIRST of several adjacent ones when ``shape`` covers them all, like the packed wq / wk / wv): inside an
+        arena-backed scope the slice then sits where the parameter sits in the arena."""
         root = self.root
         n = D._prod(shape)
         if root._bucket is not None:
+            if owner is not None and root._arena is not None:
+                at = root._arena.offset_of(owner[0], owner[1], n)
+                if at is not None:
+                    root._spans.append((at, at + n))
+                    return root._bucket.flat_view(at, shape)
             start = (root._offset + 3) // 4 * 4                # 16-byte aligned slices
             if start + n <= root._bucket.size:
                 root._offset = start + n
+                root._spans.append((start, start + n))
                 return root._bucket.flat_view(start, shape)
         g = D.empty(shape)
         if communicator().active:
@@ -448,19 +471,38 @@ class GradScope:
     def defer(self, optimizer_, obj, attribute: str, grad) -> None:
         self.root._updates.append((optimizer_, obj, attribute, grad))
 
+    def _ready_ranges(self) -> List[Tuple[int, int]]:
+        """The slices handed out since the last flush, joined where they touch (alignment gaps of up to 3 floats are
+        part of the bucket: reducing them along costs nothing).  Every slice a caller has TAKEN has been written by the
+        kernels enqueued before this call (stream order), so each range may go out."""
+        spans, self._spans = sorted(self._spans), []
+        ranges: List[List[int]] = []
+        for start, end in spans:
+            if ranges and start <= ranges[-1][1] + 3:
+                ranges[-1][1] = max(ranges[-1][1], end)
+            else:
+                if self._flushed <= start <= self._flushed + 3:
+                    start = self._flushed        # the padding behind the previous flush travels with this one: one unbroken range
+                ranges.append([start, end])
+        if ranges:
+            self._flushed = max(self._flushed, ranges[-1][1])
+        return [(a, b) for a, b in ranges if b > a]
+
     def flush(self) -> None:
         """Start exchanging every gradient produced so far (asynchronous)."""
         root = self.root
         comm = communicator()
         if not comm.active:
+            root._spans = []
             return
-        if root._bucket is not None and root._offset > root._flushed:
-            begin = root._flushed
-            root._started = True
-            comm.allreduce_async(root._bucket.flat_view(begin, [root._offset - begin]), _REDUCE_OP)
-            root._flushed = root._offset
+        if root._bucket is not None:
+            for begin, end in root._ready_ranges():
+                root._started = True
+                root.collectives += 1
+                comm.allreduce_async(root._bucket.flat_view(begin, [end - begin]), _REDUCE_OP)
         for g in root._loose:
             root._started = True
+            root.collectives += 1
             comm.allreduce_async(g.reshape(-1), _REDUCE_OP)
         root._loose = []
 
@@ -470,10 +512,19 @@ class GradScope:
             self.flush()
             comm.wait()
         updates, self._updates = self._updates, []
-        for optimizer_, obj, attribute, grad in updates:
-            optimizer_.update(obj, attribute, grad)
+        with D.coalesced_updates() as queue:
+            for optimizer_, obj, attribute, grad in updates:
+                optimizer_.update(obj, attribute, grad)
+        if queue is not None:
+            self.update_launches = queue.launches
+        GradScope.last = {'collectives': self.collectives, 'update_launches': self.update_launches,
+                          'updates': len(updates), 'arena': self._arena is not None}
         self._bucket = None
+        self._arena = None
 
 
-def grad_scope(numel_hint: int = 0) -> GradScope:
-    return GradScope(numel_hint)
+GradScope.last = None          # numbers of the most recent outermost scope that finished (diagnostics / tests); no buffers
+
+
+def grad_scope(numel_hint: int = 0, arena: Optional['D.ParamArena'] = None) -> GradScope:
+    return GradScope(numel_hint, arena)

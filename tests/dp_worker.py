@@ -85,6 +85,22 @@ def run(kind, x, t, comm):
     return params_of(layers)
 
 
+def run_decoder(norm_first, q, kv, dy, comm, scale):
+    """Two SGD steps of a TransformerDecoder on (q, kv) with the upstream gradient ``scale * dy`` (AVG of the ranks' gradients of
+    ``world * dy_shard`` = the whole batch's gradient of dy).  Returns the parameters and the collectives of each backward."""
+    parallel.set_communicator(comm, 'avg')
+    np.random.seed(0)
+    dec = npm.layers.TransformerDecoder(num_heads=2, hidden_units=24, norm_first=norm_first)
+    opt = npm.optimizer.SGDOptimizer(0.05)
+    per_backward = []
+    for _ in range(2):
+        dec(q, kv)
+        before = len(getattr(comm, 'calls', []))
+        dec(npm.device.from_host(dy * np.float32(scale)), backprop=True, optimizer_=opt)
+        per_backward.append(len(getattr(comm, 'calls', [])) - before)
+    return params_of([dec]), per_backward
+
+
 def main():
     dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{os.environ["MASTER_PORT"]}',
                             rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))
@@ -110,6 +126,32 @@ def main():
                     failures.append(f'{kind}:{name} rel err {err:.2e}')
             print(f'{kind}: {len(got)} params compared, all-reduce sizes {comm.calls[:4]}...', flush=True)
         # every rank must end with identical parameters
+        for name, a in got:
+            buf = torch.from_numpy(a.copy())
+            dist.broadcast(buf, 0)
+            if not np.array_equal(buf.numpy(), a):
+                failures.append(f'{kind}:{name} differs between ranks')
+    # TransformerDecoder (two inputs: not a Trainer layer).  Its 26 gradients travel in ONE bucket: a handful of collectives
+    # per backward (feed-forward, its norm / dense1, cross-attention, self-attention, the rest), not one per gradient (round 4)
+    for norm_first in (True, False):
+        kind = 'decoder_pre' if norm_first else 'decoder_post'
+        rng = np.random.default_rng(11)
+        q = rng.standard_normal([2 * world, 6, 8]).astype(np.float32)
+        kv = rng.standard_normal([2 * world, 9, 8]).astype(np.float32)
+        dy = (rng.standard_normal([2 * world, 6, 8]) * 1e-3).astype(np.float32)      # an upstream gradient of the size MSE's is
+        comm = GlooCommunicator()
+        parallel.set_communicator(comm)
+        got, per_backward = run_decoder(norm_first, parallel.shard(q), parallel.shard(kv), parallel.shard(dy), comm, world)
+        if not all(1 <= n <= 6 for n in per_backward):
+            failures.append(f'{kind}: {per_backward} collectives per backward (want at most 6: one bucket, a few flushes)')
+        if rank == 0:
+            want, _ = run_decoder(norm_first, q, kv, dy, parallel.Communicator(), 1)
+            for (name, a), (name2, b) in zip(got, want):
+                assert name == name2
+                err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-12)
+                if not err < 1e-5:            # fp32 sums over another partition of the batch, gradients of O(world) here
+                    failures.append(f'{kind}:{name} rel err {err:.2e}')
+            print(f'{kind}: {len(got)} params compared, {per_backward} collectives per backward, sizes {comm.calls[:5]}', flush=True)
         for name, a in got:
             buf = torch.from_numpy(a.copy())
             dist.broadcast(buf, 0)

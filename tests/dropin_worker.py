@@ -121,10 +121,22 @@ def main():
         return np.asarray(getattr(owner, '_' + attr))
 
     enc = fresh()
-    dx = enc(g['dy'], backprop=True, optimizer_=optimizer.SGDOptimizer(lr))
+    ref_sgd = optimizer.SGDOptimizer(lr)         # the REFERENCE's class, unchanged (optimizer.py:26-33)
+    seen = []
+    inner = ref_sgd.update_variable
+    ref_sgd.update_variable = lambda identifier, variable, gradient: (seen.append(identifier), inner(identifier, variable, gradient))[1]
+    import np_modeling_amd
+    sim = np_modeling_amd._C._LIB
+    before_axpy = sim.calls.count('npm_axpy')
+    dx = enc(g['dy'], backprop=True, optimizer_=ref_sgd)
     assert_close(dx, g['dx'], tol=1e-5)
     for key in keys:
         assert_close(param(enc, key), g[key + '__1'], tol=1e-5, what='sgd ' + key)
+    # Optimizer.update(obj, attribute, grad) ran once per parameter with the reference's id(obj).attribute keys -- and the 16
+    # ``variable -= lr * gradient`` of optimizer.py:32 were ONE device launch (parameters in one arena, gradients in the
+    # bucket that mirrors it: SURVEY.md section 8f rank 1)
+    assert len(seen) == 16 and len(set(seen)) == 16 and all('.' in s and s.split('.')[0].isdigit() for s in seen), seen
+    assert sim.calls.count('npm_axpy') - before_axpy == 1, sim.calls.count('npm_axpy') - before_axpy
 
     class Recorder:                              # the gradients the layers hand to an optimizer, parameters untouched
         def __init__(self):

@@ -173,6 +173,7 @@ class HostSim:
         return 0
 
     def npm_axpy(self, y, x, alpha, n):
+        self.calls.append('npm_axpy')
         _vec(y, n)[:] = _vec(y, n) + np.float32(alpha) * _vec(x, n)
         return 0
 
@@ -244,6 +245,7 @@ class HostSim:
         inside[:, :, :seq_q, :seq_kv] = True
         split = lambda a: a.reshape(nb, nh, nqt, 32, nkb, 8, 16)
         any16 = split(padded).any(axis=(3, 6))                                          # [nb, nh, nqt, nkb, 8]
+        any16[~(planes != 0).any(axis=3).all(axis=2)] = True     # a plane with a key-less query row is never skipped (npm_hip.h)
         all16 = split(padded | ~inside).all(axis=(3, 6)) & split(inside).any(axis=(3, 6))
         pack = lambda bits: (bits << np.arange(8)).sum(axis=-1).astype(np.uint8).reshape(-1)
         both = np.concatenate([pack(any16), pack(all16)])
@@ -345,6 +347,7 @@ class HostSim:
         return 0
 
     def npm_adam_step(self, var, grad, m, v, n, lr, beta1, beta2, eps, step):
+        self.calls.append('npm_adam_step')
         n = int(n)
         mm = np.ctypeslib.as_array((C.c_double * n).from_address(_addr(m)))
         vv = np.ctypeslib.as_array((C.c_double * n).from_address(_addr(v)))

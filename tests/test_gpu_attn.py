@@ -273,6 +273,10 @@ def _summary_numpy(full, every=False):
                 sub = full[:, :, 32 * qt:32 * qt + 32, 128 * kb + 16 * w:128 * kb + 16 * w + 16]
                 if sub.size:
                     out[:, :, qt, kb] |= ((sub.all(axis=(2, 3)) if every else sub.any(axis=(2, 3))).astype(np.uint8) << w)
+    if not every:
+        # a plane with a query row that has NO allowed key is never skipped: all of its "some position allowed" bytes read 0xFF
+        # (the NaNs of that row reach every dk / dv row of the plane, as np.where(mask, s, -inf) + softmax has them)
+        out[~full.any(axis=3).all(axis=2)] = 0xFF
     return out
 
 
@@ -280,11 +284,14 @@ def test_mask_summary(npm):
     """npm_mha_mask_summary against NumPy: dense, broadcast (batch / head / query) and ragged masks."""
     from np_modeling_amd import device as D
     rng = np.random.default_rng(0)
+    kinds = set()
     for shape, (b, h, sq, skv) in (([2, 3, 70, 300], (2, 3, 70, 300)), ([1, 1, 129, 129], (4, 2, 129, 129)),
                                    ([1, 2, 1, 200], (3, 2, 50, 200)), ([2, 1, 33, 16], (2, 5, 33, 16))):
         mask = rng.random(shape) < 0.02
         mask[..., :40, 130:] = False
         mask[..., 160:] |= rng.random(shape[:2] + [1, 1]) < 0.5          # ... and whole sub-tiles without an excluded position
+        mask[..., 0] |= rng.random(shape[:2] + [1]) < 0.6                 # most planes: every row keeps a key; the others have a
+        # row without any -- both kinds must occur over the four shapes (asserted below)
         dev = D.AttnMask(mask, b, h, sq, skv)
         assert dev.summary is not None
         nb, nh = shape[0], shape[1]
@@ -294,6 +301,8 @@ def test_mask_summary(npm):
         np.testing.assert_array_equal(got[1], _summary_numpy(full, every=True))
         assert dev.summary_all_offset == got[0].size
         assert dev.summary_strides == (0 if nb == 1 else got[0, 0].size, 0 if nh == 1 else got[0, 0, 0].size)
+        kinds.update(full.any(axis=3).all(axis=2).reshape(-1).tolist())
+    assert kinds == {True, False}, 'the shapes above must cover planes with and without a key-less row'
 
 
 @pytest.mark.parametrize('d', [16, 64, 128])
@@ -345,33 +354,45 @@ def test_core_tile_skipping_changes_nothing(npm, d, kind, bwd_kernel):
                 assert (~written).any()                             # ... and whole tiles were not
 
 
-def test_core_query_tile_without_any_key(npm):
-    """A whole 32-query tile whose rows have no key at all: no key block visits it.  Forward: those rows are NaN (the softmax
-    of a row of -inf), the others exact; backward: their dq rows are ZERO (filled at the end) and, unlike the unskipped run,
-    they do not poison dk / dv."""
+@pytest.mark.parametrize('rows', ['whole tile', 'one row', 'two rows in two tiles'])
+def test_core_rows_without_any_key_are_never_skipped(npm, rows, bwd_kernel):
+    """Query rows with NO allowed key: np.where(mask, s, -inf) + softmax makes such a row NaN -- its ctx and dq rows, and through
+    P = NaN every dk / dv row of its (batch, head).  ONE rule in every kernel and mode (round-4 advisor): with the tile summary
+    the results are those of the unskipped run, bit for bit, NaNs included -- npm_mha_mask_summary marks every tile of a plane
+    that has such a row as "visit" -- whether the rows fill a whole 32-query tile (round 4 zero-filled their dq and kept dk / dv
+    clean) or not.  The other head of the same batch is not touched by any of it."""
     rng = np.random.default_rng(5)
     b, h, sq, skv, d = 1, 2, 96, 160, 128
     q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
     k, v = (rng.standard_normal([b, skv, h, d]).astype(np.float32) for _ in range(2))
     dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
     mask = np.ones([b, h, sq, skv], dtype=bool)
-    mask[:, :, 32:64, :] = False
+    mask[0, 1] = (np.arange(skv)[None, :] <= np.arange(sq)[:, None] + 40)         # head 1: tiles to skip, no key-less row
+    dead = {'whole tile': slice(32, 64), 'one row': slice(37, 38), 'two rows in two tiles': [5, 70]}[rows]
+    mask[0, 0, dead, :] = False
     scale = 1.0 / np.sqrt(d)
-    keep = np.ones(sq, dtype=bool)
-    keep[32:64] = False
-    sub = [x.astype(np.float64) for x in (q[:, keep], k, v)]
-    ctx, lse, probs = O.attention_core_fwd(*sub, scale)
-    dq, dk, dv = O.attention_core_bwd(*sub, probs, dctx[:, keep].astype(np.float64), scale)
+    sub = [x.astype(np.float64) for x in (q[:, :, 1:], k[:, :, 1:], v[:, :, 1:])]
+    ctx1, _, probs1 = O.attention_core_fwd(*sub, scale, mask[:, 1:])
+    dq1, dk1, dv1 = O.attention_core_bwd(*sub, probs1, dctx[:, :, 1:].astype(np.float64), scale)
+    alive = np.ones(sq, dtype=bool)
+    alive[dead] = False
     for save in (False, True):
         got = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save)
-        assert np.isnan(got['ctx'][:, ~keep]).all()
-        assert_close(got['ctx'][:, keep], ctx, tol=2e-6)
-        from np_modeling_amd import _C
-        if _C.last_attn_kernel().startswith('mha_bwd8_kernel'):
-            np.testing.assert_array_equal(got['dq'][:, ~keep], 0.0)
-            assert_close(got['dq'][:, keep], dq, tol=3e-6)
-            assert_close(got['dk'], dk, tol=3e-6)
-            assert_close(got['dv'], dv, tol=3e-6)
+        plain = _run_core(npm, q, k, v, scale, dctx=dctx, mask=mask, save=save, skip=False)
+        same_kernel = not (bwd_kernel == 2 and d == 128 and save)      # (see test_core_tile_skipping_changes_nothing)
+        for name in ('ctx', 'lse', 'dq', 'dk', 'dv'):
+            assert (np.isnan(got[name]) == np.isnan(plain[name])).all(), f'{rows} {name} save={save}: NaNs differ from the unskipped run'
+            if same_kernel or name in ('ctx', 'lse'):
+                np.testing.assert_array_equal(got[name][:, :, :1], plain[name][:, :, :1], err_msg=f'{rows} {name} save={save}')   # head 0: unskipped
+        # what NumPy gives: the dead rows NaN, and with them all of head 0's key gradients; every other row of ctx exact
+        assert np.isnan(got['ctx'][0, ~alive, 0]).all() and np.isfinite(got['ctx'][0, alive, 0]).all()
+        assert np.isnan(got['dq'][0, ~alive, 0]).all()
+        assert np.isnan(got['dk'][0, :, 0]).all() and np.isnan(got['dv'][0, :, 0]).all()
+        # head 1 (its own plane of the summary, with tiles that ARE skipped): finite and right
+        assert_close(got['ctx'][:, :, 1:], ctx1, tol=2e-6)
+        for name, want in (('dq', dq1), ('dk', dk1), ('dv', dv1)):
+            assert np.isfinite(got[name][:, :, 1:]).all()
+            assert_close(got[name][:, :, 1:], want, tol=3e-6, what=f'{rows} head 1 {name} save={save}')
 
 
 def test_core_row_without_any_key_is_nan_and_only_that_row(npm):

@@ -265,7 +265,8 @@ def test_data_parallel_equivalence_gloo(world):
             raise
         outs.append(out)
     assert all(p.returncode == 0 for p in procs), '\n'.join(outs)
-    assert 'encoder_post' in outs[0]
+    assert 'encoder_post' in outs[0] and 'decoder_post' in outs[0]
+    assert 'collectives per backward' in outs[0]
 
 
 def _clean_env(**extra):
@@ -788,3 +789,126 @@ def test_rank_dies_with_its_launcher_only(monkeypatch):
     assert launch.die_with_launcher() is True and calls == [1]
     monkeypatch.setenv('NPM_DIE_WITH_PARENT', '0')
     assert launch.die_with_launcher() is False and calls == [1]
+
+
+# ---- one optimizer launch per backward --------------------------------------------------
+def _encoder_step(npm, optimizer_, steps=2, rebind=None, norm_first=True, decoder=False):
+    """``steps`` forward + backward steps of a small encoder (or decoder) on the simulator; returns (parameters, number of
+    optimizer launches of the last backward, what GradScope recorded about it)."""
+    from np_modeling_amd import parallel
+    np.random.seed(3)
+    rng = np.random.default_rng(3)
+    cls = npm.layers.TransformerDecoder if decoder else npm.layers.TransformerEncoder
+    layer = cls(num_heads=2, hidden_units=20, norm_first=norm_first)
+    x = rng.standard_normal([2, 5, 8]).astype(np.float32)
+    kv = rng.standard_normal([2, 7, 8]).astype(np.float32)
+    dy = rng.standard_normal([2, 5, 8]).astype(np.float32)
+    args = (x, kv) if decoder else (x,)
+    launches = None
+    for step in range(steps):
+        layer(*args)
+        if rebind and step == 0:
+            rebind(layer)
+        sim = npm._C._LIB
+        before = sim.calls.count('npm_axpy') + sim.calls.count('npm_adam_step')
+        layer(dy, backprop=True, optimizer_=optimizer_)
+        launches = sim.calls.count('npm_axpy') + sim.calls.count('npm_adam_step') - before
+    names = ('_w', '_b', '_wq', '_wk', '_wv', '_wo', '_bq', '_bk', '_bv', '_bo', '_gamma', '_beta')
+    return [np.asarray(p).copy() for p in parallel.parameters(layer)], launches, dict(parallel.GradScope.last), layer
+
+
+@pytest.mark.parametrize('norm_first', [True, False])
+@pytest.mark.parametrize('kind', ['sgd', 'adam', 'reference sgd'])
+def test_one_optimizer_launch_per_encoder_backward(npm, monkeypatch, kind, norm_first):
+    """The 16 parameters of an encoder sit back to back in one arena, ordered as backward produces their gradients; the
+    gradient bucket mirrors it, and the 16 ``optimizer_.update(obj, attribute, grad)`` calls of a backward -- still made one by
+    one, with the reference's ``id(obj).attribute`` keying -- run as ONE axpy / ONE Adam kernel.  Bit-equal to the
+    per-parameter launches (NPM_COALESCE_UPDATES=0).  'reference sgd': the reference's own class, verbatim behaviour."""
+    D = npm.device
+
+    class ReferenceSGD:                   # reference optimizer.py:12-33, restated: getattr -> variable -= lr * gradient -> setattr
+        def __init__(self, lr):
+            self._learning_rate, self.keys = lr, []
+
+        def update(self, obj, attribute, gradient):
+            self.keys.append(f'{id(obj)}.{attribute}')
+            variable = getattr(obj, attribute)
+            variable -= self._learning_rate * gradient
+            setattr(obj, attribute, variable)
+
+    def make():
+        return {'sgd': lambda: npm.optimizer.SGDOptimizer(0.05), 'adam': lambda: npm.optimizer.AdamOptimizer(0.01),
+                'reference sgd': lambda: ReferenceSGD(0.05)}[kind]()
+
+    monkeypatch.setattr(D, 'COALESCE_UPDATES', True)
+    opt = make()
+    got, launches, last, layer = _encoder_step(npm, opt, norm_first=norm_first)
+    assert launches == 1 and last['update_launches'] == 1 and last['updates'] == 16 and last['arena'], (launches, last)
+    assert layer._arena.live() == 16
+    if kind == 'reference sgd':
+        assert len(opt.keys) == 32 and len(set(opt.keys)) == 16      # update() called per parameter, both steps, same keys
+    if kind == 'adam':
+        assert len(opt._state) == 16 and all(entry[0] == 3 for entry in opt._state.values())    # per-identifier state, two steps each
+    monkeypatch.setattr(D, 'COALESCE_UPDATES', False)
+    want, launches, last, layer = _encoder_step(npm, make(), norm_first=norm_first)
+    assert launches == 16 and last['update_launches'] is None and layer._arena is None
+    assert len(got) == len(want) == 16
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_rebound_parameter_leaves_the_arena(npm, monkeypatch):
+    """Weight binders assign arrays into private attributes (reference layers/utils.py:52-88).  Such a parameter is no longer
+    part of the arena: it is updated by a launch of its own, the others still together (split where it used to sit); results
+    equal to the per-parameter path."""
+    D = npm.device
+
+    def rebind(enc):
+        enc._dense1._linear._w = np.asarray(enc._dense1._linear._w) * np.float32(0.5)      # a host array, like a binder's
+        enc._self_attention._wk = D.from_host(np.asarray(enc._self_attention._wk) * np.float32(2.0))   # breaks the packed q/k/v too
+
+    monkeypatch.setattr(D, 'COALESCE_UPDATES', True)
+    got, launches, last, layer = _encoder_step(npm, npm.optimizer.SGDOptimizer(0.05), rebind=rebind)
+    assert layer._arena.live() == 14
+    assert 3 <= launches <= 6 and last['updates'] == 16, (launches, last)
+    monkeypatch.setattr(D, 'COALESCE_UPDATES', False)
+    want, launches, _, _ = _encoder_step(npm, npm.optimizer.SGDOptimizer(0.05), rebind=rebind)
+    assert launches == 16
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a, b)
+
+
+def test_decoder_bucket_and_single_launch(npm, monkeypatch):
+    """TransformerDecoder: 26 parameters in one arena, one optimizer launch per backward; with two ranks (a recording
+    transport) its gradients go out in one bucket as five collectives (feed-forward | norm / dense1 | cross-attention |
+    self-attention | the rest) -- round 4 opened the scope without a size and every gradient was a collective of its own."""
+    from np_modeling_amd import parallel
+    D = npm.device
+    monkeypatch.setattr(D, 'COALESCE_UPDATES', True)
+    for norm_first in (True, False):
+        got, launches, last, layer = _encoder_step(npm, npm.optimizer.SGDOptimizer(0.05), norm_first=norm_first, decoder=True)
+        assert launches == 1 and last['updates'] == 26 and layer._arena.live() == 26, (launches, last)
+    sent = []
+
+    class Recorder(parallel.Communicator):
+        rank, world_size = 0, 2
+
+        def allreduce_async(self, flat, op):
+            sent.append((flat.ptr, flat.size))
+
+        def wait(self):
+            pass
+
+    parallel.set_communicator(Recorder())
+    try:
+        for norm_first in (True, False):
+            sent.clear()
+            _, launches, last, layer = _encoder_step(npm, npm.optimizer.SGDOptimizer(0.05), steps=1, norm_first=norm_first, decoder=True)
+            assert last['collectives'] == len(sent) and 4 <= len(sent) <= 6, sent
+            total = sum(n for _, n in sent)
+            assert layer._arena.size <= total <= layer._arena.size + 64        # every gradient once; the padding travels along
+            starts = sorted(p for p, _ in sent)
+            assert all(b > a for a, b in zip(starts, starts[1:]))               # disjoint, ascending: arena order = production order
+            assert launches == 1
+    finally:
+        parallel.set_communicator(None)
