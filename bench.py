@@ -144,19 +144,30 @@ def alt_roofline(timer, per_product=6, kernel=None):
 
 
 def load_pmc_traffic(args):
-    """HBM-side bytes per GEMM launch from the committed rocprofv3 PMC passes (profiles/summarize_pmc.py); PMC
-    counters cannot be read from inside the process, so this is the value of the last profiled run of this same
-    default workload, or null for any other shape."""
+    """Bytes per GEMM launch that leave the L2s, from the rocprofv3 PMC passes of THIS build (profiles/summarize_pmc.py): PMC
+    counters cannot be read from inside the process, so the figure is a property of a profiling session -- the JSON names it
+    (``session``, ``collected``) and the sources its library was built from (``source_id``).  A file collected for other
+    sources, or a library older than its sources, gives null: numbers of another build are not this run's."""
+    from np_modeling_amd import _C
     path = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     default = (args.batch, args.seq, args.features, args.heads, args.hidden) == (256, 512, 1024, 8, 4096)
-    if not (default and os.path.exists(path)):
-        return None, None
+    if not default:
+        return None, 'not the default workload: no PMC session exists for this shape'
+    if not os.path.exists(path):
+        return None, 'profiles/pmc_traffic.json is missing (tools/refresh_profiles.sh collects it)'
     with open(path) as f:
         data = json.load(f)
-    return data['gemm_family_bytes_per_launch'], ('profiles/pmc_traffic.json: (2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes: requests that leave the '
-                                                 'L2s (fabric side), Infinity-Cache hits included.  An HBM-side figure cannot be taken on this pool: rocprofv3 exposes no '
-                                                 'memory-controller / Infinity-Cache counters on gfx950 and the SMU mem_busy figure reads 0 (profiles/r03_hbm_side.log, '
-                                                 'profiles/r03_pmc_tcc_ffn_dw.log)')
+    now = _C.source_id()
+    if data.get('source_id') != now:
+        return None, (f'profiles/pmc_traffic.json was collected for sources {data.get("source_id", "(unrecorded: before round 5)")} in session '
+                      f'{data.get("session", "?")}; this build is {now}: stale, rerun tools/refresh_profiles.sh')
+    if not _C.library_is_current():
+        return None, 'libnpm_hip.so is older than its sources: rebuild before quoting a profile for them'
+    return data['gemm_family_bytes_per_launch'], (
+        f'profiles/pmc_traffic.json, session {data.get("session")} ({data.get("collected")}), sources {now} = this build: '
+        '(2*FETCH_SIZE + WRITE_SIZE)*1024, separate rocprofv3 --pmc passes: requests that leave the L2s (fabric side), Infinity-Cache '
+        'hits included.  An HBM-side figure cannot be taken on this pool: rocprofv3 exposes no memory-controller / Infinity-Cache '
+        'counters on gfx950 and the SMU mem_busy figure reads 0 (profiles/r03_hbm_side.log, profiles/r03_pmc_tcc_ffn_dw.log)')
 
 
 def main():

@@ -136,6 +136,7 @@ enum {
     NPM_TUNE_ATTN_FWD8 = 17,         /* attention forward: 2 mha_fwd8_kernel (8 waves per block on the 16x16x4 MFMA, four waves per SIMD) for every head size; 1 below head size 128 only; 0 the 4-wave 32x32x2 mha_fwd_kernel always */
     NPM_TUNE_GEMM_SPLIT_GENS = 18,   /* split-K of tall-K products (weight gradients): 1 (default) for A-heavy products that also sum A's columns, a K range longer than 768 K tiles is cut further when that makes whole generations of resident blocks (3 x 4 per CU: the packed q/k/v weight gradient 6.00 -> 5.71 ms); 0 one generation of three blocks per CU always (round 3) */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
+    NPM_TUNE_LN_NT_SPLIT = 19,       /* LayerNorm at d in (512, 1024]: backward mode + 4 * forward mode; a mode: 0 nontemporal hint on loads and stores, 1 on the loads only, 2 on the stores only.  Default 1 (backward: its dx is read at once by the GEMM behind it; measured inside the encoder step, profiles/r05_ln_nt_split.log) */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);

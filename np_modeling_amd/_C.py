@@ -228,6 +228,35 @@ def load_comm_library(path: str = RCCL_LIB_PATH):
     return _bind(C.CDLL(path, mode=C.RTLD_GLOBAL), COMM_SIGNATURES, _COMM_SPECIAL)
 
 
+def source_id() -> str:
+    """16 hex digits over the kernel sources and headers the libraries are built from (csrc/*, include/*.h).  A profile that is
+    not taken inside the measuring process (the PMC traffic figure of bench.py) records it, and whoever quotes the profile
+    compares: numbers of another build are not this build's."""
+    import glob
+    import hashlib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    digest = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(root, 'np_modeling_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'np_modeling_amd', 'csrc', '*.h'))
+                   + glob.glob(os.path.join(root, 'np_modeling_amd', 'csrc', '*.cpp')) + glob.glob(os.path.join(root, 'include', '*.h')))
+    for path in files:
+        digest.update(os.path.basename(path).encode())
+        with open(path, 'rb') as f:
+            digest.update(f.read())
+    return digest.hexdigest()[:16]
+
+
+def library_is_current() -> bool:
+    """Whether the built libnpm_hip.so is at least as new as every source it is made of (the Makefile's own rule)."""
+    import glob
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not os.path.exists(LIB_PATH):
+        return False
+    built = os.path.getmtime(LIB_PATH)
+    sources = glob.glob(os.path.join(root, 'np_modeling_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'np_modeling_amd', 'csrc', '*.h')) \
+        + [os.path.join(root, 'include', 'npm_hip.h')]
+    return all(os.path.getmtime(p) <= built for p in sources)
+
+
 def lib():
     """The bound, device-initialised library.  Raises if there is no library or no GPU."""
     global _LIB, _DEVICE

@@ -1027,8 +1027,10 @@ mha_bwd_kernel(const MhaArgs p) {
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float pr = fast_exp2(fmaf(S[r], c, -Lr[r]));
-                if (MASK && mk[r] == 0) pr = 0.f;      // (a key or query beyond the end reads 0 too: its P is never used)
+                // an excluded position has the score -inf (np.where(mask, scaled, -inf)): P = 0 -- except in a row with NO allowed
+                // key, whose LSE is -inf too: P = NaN there, as NumPy's softmax of a row of -inf, and as the saved scores (which
+                // carry the -inf) give it.  (a key or query beyond the end reads 0 too: its P is never used)
+                const float pr = fast_exp2(fmaf((MASK && mk[r] == 0) ? -INFINITY : S[r], c, -Lr[r]));
                 P[r] = pr;
                 dS[r] = pr * (dP[r] - Dr[r]);                 // dP and delta carry the 1 / sqrt(Dk) already
                 sDS[ebs[(r >> 2) & 1][r & 3] + 8 * (r >> 2) * 128] = dS[r];
@@ -1777,8 +1779,8 @@ mha_bwd8_kernel(const MhaArgs p) {
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        float pr = fast_exp2(fmaf(S[t][r], c, -Lr[t][r]));
-                        if (masked_sub && mk[t][r] == 0) pr = 0.f;
+                        // (an excluded position: score -inf, so P = 0 -- and NaN in a row without any allowed key, see mha_bwd_kernel)
+                        const float pr = fast_exp2(fmaf((masked_sub && mk[t][r] == 0) ? -INFINITY : S[t][r], c, -Lr[t][r]));
                         P[t][r] = pr;
                         dS[t][r] = pr * dP[t][r];
                         tDS[wsS[r] + t * SROWS16] = dS[t][r];

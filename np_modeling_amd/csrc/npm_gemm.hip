@@ -457,6 +457,7 @@ extern "C" int npm_set_tuning(int knob, int value) {
             return npm_conv_set_math(value == 3 ? 2 : value);        // the conv kernels have no f16 form: the bf16 split
         case NPM_TUNE_GEMM_WAVE_PRIO: g_wave_prio = value; return npm_conv_set_wave_prio(value);
         case NPM_TUNE_LN_BWD_BLOCKS: npm::set_ln_bwd_blocks(value); return NPM_OK;
+        case NPM_TUNE_LN_NT_SPLIT: npm::set_ln_nt_split(value); return NPM_OK;
         case NPM_TUNE_EW_GRID_CAP: npm::set_ew_grid_cap(value); return NPM_OK;
         case NPM_TUNE_ATTN_STAGGER: return npm_attn_set_stagger(value);
         case NPM_TUNE_ATTN_BWD16: return npm_attn_set_bwd16(value);

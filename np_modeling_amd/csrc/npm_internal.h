@@ -25,6 +25,7 @@ int fail(int code, const char *fmt, ...);
 // out[c] = sum_r x[r * ld + c], two-stage, fixed order (npm_rowops.hip)
 int colsum_launch(const float *x, float *out, long rows, long cols, long ld);
 void set_ln_bwd_blocks(int blocks_per_cu);
+void set_ln_nt_split(int mode);
 void set_ew_grid_cap(int blocks);
 void set_stream_nt(int on);
 // streaming tensors of at least 32 MB move with the nontemporal cache hint (npm_rowops.hip; NPM_TUNE_STREAM_NT)

@@ -12,6 +12,11 @@
 namespace {
 
 int g_ln_bwd_blocks_per_cu = 4;     // NPM_TUNE_LN_BWD_BLOCKS
+// NPM_TUNE_LN_NT_SPLIT = backward mode + 4 * forward mode; a mode: 0 nontemporal hint on loads and stores, 1 on the loads only, 2 on
+// the stores only (d in (512, 1024] -- the encoder's rows; other widths take mode 0).  Default 1 + 4 * 0: measured INSIDE the
+// encoder step (profiles/r05_ln_nt_split.log) the backward runs 0.377 -> 0.362 ms with its dx stored under the default policy
+// (the GEMM behind it reads dx at once), although from cold caches and alone the same variant is the slower one (5.1 against 5.5 TB/s)
+int g_ln_nt_split = 1;
 int g_stream_nt = 1;                // NPM_TUNE_STREAM_NT
 constexpr int COLSUM_BLOCKS_PER_CU = 8;     // whole-line column sums: grid = this x CUs (2 .. 64 measured within 3 % of each other)
 
@@ -514,7 +519,7 @@ attn_rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b, flo
 }
 
 // ---- LayerNorm ---------------------------------------------------------------------
-template <int VPL, bool NT>
+template <int VPL, bool NT, bool NTS = NT>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                      float eps, long rows, int d, float *__restrict__ z, float *__restrict__ mean_out,
@@ -551,7 +556,7 @@ layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamm
             v[j].w = gm.w * ((v[j].w - mean) * rstd) + bt.w;
         }
     }
-    store_row<VPL, NT>(z + row * d, nvec, lane, v);
+    store_row<VPL, NTS>(z + row * d, nvec, lane, v);
     if (lane == 0) { mean_out[row] = mean; rstd_out[row] = rstd; }
 }
 
@@ -577,7 +582,7 @@ layernorm_fwd_generic(const float *__restrict__ x, const float *__restrict__ gam
 // Backward: each wave walks rows (grid-stride) and keeps its dgamma/dbeta partials for the
 // columns it owns in registers; every wave writes one partial row and a column sum over
 // the wave partials (fixed order, reproducible) finishes the job.
-template <int VPL, bool NT>
+template <int VPL, bool NT, bool NTS = NT>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
                      const float *__restrict__ rstd, const float *__restrict__ gamma,
@@ -625,7 +630,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
             o.z = rs * (g[j].z - m1 - yh[j].z * m2); o.w = rs * (g[j].w - m1 - yh[j].w * m2);
             if (c < nvec) {
                 if (residual) { o.x += res[j].x; o.y += res[j].y; o.z += res[j].z; o.w += res[j].w; }
-                stg4<NT>(dx + row * d + 4 * c, o);
+                stg4<NTS>(dx + row * d + 4 * c, o);
             }
         }
     }
@@ -688,6 +693,7 @@ layernorm_bwd_dx_generic(const float *__restrict__ dz, const float *__restrict__
 
 namespace npm {
 void set_ln_bwd_blocks(int v) { g_ln_bwd_blocks_per_cu = v > 0 ? v : 4; }
+void set_ln_nt_split(int v) { g_ln_nt_split = v; }
 void set_stream_nt(int v) { g_stream_nt = v != 0; }
 bool stream_nt_enabled(size_t bytes) { return stream_nt(bytes); }
 void set_ew_grid_cap(int v) { g_ew_grid_cap = v > 0 ? v : (1 << 20); }
@@ -831,7 +837,12 @@ int npm_layernorm_fwd(const float *x, const float *gamma, const float *beta, flo
     NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
     hipStream_t s = npm::ctx().stream;
     const bool fast = d % 4 == 0 && d <= 4096 && aligned16(x) && aligned16(z) && aligned16(gamma) && aligned16(beta);
-    if (fast) {
+    const int fwd_mode = g_ln_nt_split >> 2;
+    if (fast && fwd_mode && d > 512 && d <= 1024 && stream_nt(sizeof(float) * (size_t)rows * (size_t)d)) {
+        const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+        if (fwd_mode == 1) hipLaunchKernelGGL((layernorm_fwd_kernel<4, true, false>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd);
+        else hipLaunchKernelGGL((layernorm_fwd_kernel<4, false, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd);
+    } else if (fast) {
         NPM_ROW_DISPATCH(layernorm_fwd_kernel, d, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd);
     } else {
         const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
@@ -862,7 +873,11 @@ int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const 
         int rc = part.alloc(sizeof(float) * 2 * (size_t)grid * d);
         if (rc) return rc;
         float *pp = (float *)part.ptr;                     // [grid][2 d]: dgamma partials | dbeta partials
-        if (stream_nt(sizeof(float) * (size_t)rows * (size_t)d))
+        if (stream_nt(sizeof(float) * (size_t)rows * (size_t)d) && (g_ln_nt_split & 3) == 1 && d > 512 && d <= 1024)
+            hipLaunchKernelGGL((layernorm_bwd_kernel<4, true, false>), dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
+        else if (stream_nt(sizeof(float) * (size_t)rows * (size_t)d) && (g_ln_nt_split & 3) == 2 && d > 512 && d <= 1024)
+            hipLaunchKernelGGL((layernorm_bwd_kernel<4, false, true>), dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
+        else if (stream_nt(sizeof(float) * (size_t)rows * (size_t)d))
             NPM_ROW_DISPATCH_NT(layernorm_bwd_kernel, true, d, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
         else
             NPM_ROW_DISPATCH_NT(layernorm_bwd_kernel, false, d, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);

@@ -3,7 +3,10 @@
 
     rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d A -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer
     rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d B -- python3 bench.py ... (same)
-    python profiles/summarize_pmc.py A/*/*_counter_collection.csv B/*/*_counter_collection.csv > profiles/pmc_traffic.json
+    python profiles/summarize_pmc.py A/*/*_counter_collection.csv B/*/*_counter_collection.csv [--session NAME] > profiles/pmc_traffic.json
+
+The result names the session it comes from (``session``) and the sources the measured library was built from
+(``source_id`` = np_modeling_amd._C.source_id()); bench.py quotes the figure only for that build.
 
 Units and corrections follow /opt/skills/guides/MI355X_MICROARCH.md section HBM: both counters are in KiB; on gfx950
 FETCH_SIZE reports exactly half of the bytes of wide (16 B/lane) coalesced streaming reads, so it is doubled;
@@ -26,6 +29,15 @@ def per_kernel(path):
 
 
 def main():
+    import datetime
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from np_modeling_amd import _C
+    session = 'unnamed'
+    if '--session' in sys.argv:
+        at = sys.argv.index('--session')
+        session = sys.argv[at + 1]
+        del sys.argv[at:at + 2]
     fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
     kernels = {}
     for name in fetch:
@@ -36,7 +48,11 @@ def main():
     gemm = {k: v for k, v in kernels.items() if k.startswith('sgemm_')}      # bench.py's roofline kernel
     n = sum(v['launches'] for v in gemm.values())
     family = sum(v['bytes_per_launch'] * v['launches'] for v in gemm.values()) / max(n, 1)
-    print(json.dumps(dict(gemm_family_bytes_per_launch=family, gemm_family_launches=n, kernels=kernels,
+    print(json.dumps(dict(gemm_family_bytes_per_launch=family, gemm_family_launches=n,
+                          session=session, collected=datetime.datetime.now().isoformat(timespec='seconds'),
+                          source_id=_C.source_id(), library_current=_C.library_is_current(),
+                          command='rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python3 bench.py --steps 2 --warmup 1 '
+                                  '--no-cpu-baseline --no-kernel-timer --no-alt-math --no-configs', kernels=kernels,
                           note='FETCH_SIZE doubled (gfx950 correction), WRITE_SIZE exact, KiB units; includes Infinity-Cache hits'),
                      indent=1))
 

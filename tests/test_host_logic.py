@@ -912,3 +912,31 @@ def test_decoder_bucket_and_single_launch(npm, monkeypatch):
             assert launches == 1
     finally:
         parallel.set_communicator(None)
+
+
+def test_bench_traffic_figure_belongs_to_this_build(monkeypatch):
+    """bench.py quotes roofline.traffic from profiles/pmc_traffic.json only when that file was collected for the sources this
+    build is made of (np_modeling_amd._C.source_id) -- the figure of another build is reported as null with the reason, and the
+    source names the profiling session."""
+    import argparse
+    import json
+    import bench
+    from np_modeling_amd import _C
+    args = argparse.Namespace(batch=256, seq=512, features=1024, heads=8, hidden=4096)
+    with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+        recorded = json.load(f)
+    monkeypatch.setattr(_C, 'library_is_current', lambda: True)
+    monkeypatch.setattr(_C, 'source_id', lambda: recorded.get('source_id', 'none recorded'))
+    value, source = bench.load_pmc_traffic(args)
+    if 'source_id' in recorded:
+        assert value == recorded['gemm_family_bytes_per_launch'] and recorded['session'] in source and 'this build' in source
+    monkeypatch.setattr(_C, 'source_id', lambda: '0123456789abcdef')
+    value, source = bench.load_pmc_traffic(args)
+    assert value is None and 'stale' in source and '0123456789abcdef' in source
+    monkeypatch.setattr(_C, 'source_id', lambda: recorded.get('source_id', 'x'))
+    monkeypatch.setattr(_C, 'library_is_current', lambda: False)
+    value, source = bench.load_pmc_traffic(args)
+    assert value is None
+    args.batch = 8
+    assert bench.load_pmc_traffic(args)[0] is None
+    assert len(_C.source_id.__wrapped__()) == 16 if hasattr(_C.source_id, '__wrapped__') else True

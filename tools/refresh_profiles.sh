@@ -6,11 +6,21 @@
 # the decoder line, the HBM-side probe and the TCC request counters of the weight-gradient GEMM.
 set -o pipefail
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-R=${NPM_ROUND:-r04}
+R=${NPM_ROUND:-r05}
 OUT=$REPO/gpurun_out/profiles_new
 mkdir -p "$OUT"
 cd "$REPO"
+# FIRST the PMC traffic passes: the bench line below quotes their figure (roofline.traffic), so both come from THIS session and
+# THIS build (profiles/pmc_traffic.json carries the session name and the sources' id; bench.py refuses any other build's)
+echo "== PMC traffic (two passes)"
+( cd /tmp && export TMPDIR=/tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-alt-math --no-configs > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err" || exit 1
+  done ) || exit 1
+python3 profiles/summarize_pmc.py "$OUT"/pmc_FETCH_SIZE/*/*_counter_collection.csv "$OUT"/pmc_WRITE_SIZE/*/*_counter_collection.csv --session "${R}:$(date +%Y-%m-%dT%H:%M):$(hostname)" > "$OUT/pmc_traffic.json" || exit 1
+cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
 echo "== bench (default command)"; timeout -k 10 500 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err" || exit 1
+python3 -c "import json; d=json.load(open('$OUT/${R}_bench.json')); t=json.load(open('$OUT/pmc_traffic.json')); assert d['roofline']['traffic'] == t['gemm_family_bytes_per_launch'], (d['roofline']['traffic'], d['roofline'].get('traffic_source')); print('roofline.traffic =', d['roofline']['traffic'], 'from', t['session'])" || exit 1
 echo "== clock / power during 60 steps"; tools/clock_sampler.sh "$OUT/clocks_f32.log" -- timeout -k 10 200 python bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-alt-math --no-configs > "$OUT/bench_60.json" 2>/dev/null
 { echo "bench.py --steps 60 --warmup 3, sysfs freq1_input / power1_input of the loaded card (tools/clock_sampler.sh)";
   echo "math f32: $(python3 -c "import json;d=json.load(open('$OUT/bench_60.json'));print(round(d['value'],1),'samples/s',round(d['ms_per_step'],2),'ms/step')")  $(python3 tools/clock_summary.py $OUT/clocks_f32.log)"; } > "$OUT/${R}_clock_power.log"
@@ -48,12 +58,7 @@ echo "== rocprofv3 kernel trace of the other configs (C2, C3, C4, DEC)"
 cd /tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_cfg" -- python3 "$REPO/tools/config_bench.py" --min-seconds 0.3 > "$OUT/cfg_under_rocprof.log" 2> "$OUT/prof_cfg.err" && cp "$OUT"/prof_cfg/*/*_kernel_stats.csv "$OUT/${R}_config_kernel_stats.csv"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/prof_dec" -- python3 "$REPO/tools/config_bench.py" --only DEC --min-seconds 0.3 > "$OUT/dec_under_rocprof.log" 2> "$OUT/prof_dec.err" && cp "$OUT"/prof_dec/*/*_kernel_stats.csv "$OUT/${R}_decoder_kernel_stats.csv"
-echo "== PMC traffic (two passes)"
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 200 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$OUT/pmc_$c" -- python3 "$REPO/bench.py" --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer --no-alt-math --no-configs > "$OUT/pmc_$c.json" 2> "$OUT/pmc_$c.err" || exit 1
-done
 cd "$REPO"
-python3 profiles/summarize_pmc.py "$OUT"/pmc_FETCH_SIZE/*/*_counter_collection.csv "$OUT"/pmc_WRITE_SIZE/*/*_counter_collection.csv > "$OUT/pmc_traffic.json"
 echo "== TCC request counters of the FFN weight-gradient GEMM (DRAM-destined vs all; L2 hit / miss)"
 tools/pmc/one_shape.sh "ffn_dw_TN M=1024" 10=0 "$OUT/pmc_tn" "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_32B_sum" "TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum TCC_EA0_RD_UNCACHED_32B_sum" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_DRAM_sum TCC_EA0_WRREQ_64B_sum" > "$OUT/${R}_pmc_tcc_ffn_dw.log" 2>&1
 echo "== SQ / TCC counters of the kernels that are in the step and in the configs"
