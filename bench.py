@@ -352,6 +352,14 @@ def main():
                                 'GBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9, 'frac_of_8TBps': v['bytes'] / (v['ms'] * 1e-3) / 1e9 / HBM_PEAK_GBS}
                             for k, v in sorted(summary.items()) if not k.startswith(MFMA_BOUND) and v['ms'] > 0},
         }
+        if 'mha_core_bwd' in result['roofline']['other_mfma_kernels']:
+            rowdot = D.ATTN_ROWDOT and args.math == 'f32' and args.features // args.heads == 128
+            result['roofline']['other_mfma_kernels']['mha_core_bwd']['row_terms'] = (
+                'delta = dctx . ctx per query and head comes out of the epilogue of the dctx = dy wo GEMM (NPM_EPI_ROWDOT: one of the four '
+                'sgemm_NN launches of a step carries it, its cost is inside by_layout.sgemm_NN); this entry is the attention backward '
+                'kernel plus a 4 MB log2(e)*LSE pass.  Rounds 3-4 ran a pass over dctx and ctx in front of the kernel instead '
+                '(0.21 of their 4.45 ms; NPM_ATTN_ROWDOT=0 restores it)' if rowdot else
+                'delta = dctx . ctx by a pass over dctx and ctx in front of the kernel (mha_rowterms_kernel), included in this entry')
     def alt_region(mode):
         """A further timed region, same K steps, same barriers, under another arithmetic of the matrix products."""
         npm.set_math(mode)

@@ -82,8 +82,15 @@ enum {
     NPM_EPI_RELU_SAVE = 4,   /* aux[m,n] = v; C = max(v,0)                 (activations.py:14-15) */
     NPM_EPI_RELU_MASK = 8,   /* C = aux[m,n] >= 0 ? v : 0                  (activations.py:19) */
     NPM_EPI_RELU = 16,       /* C = max(v,0), pre-activation not kept (inference) */
-    NPM_EPI_SOFTMAX_BWD = 32 /* C = alpha * aux[m,n] * (acc - rowvec[m]): softmax backward with the row term
+    NPM_EPI_SOFTMAX_BWD = 32,/* C = alpha * aux[m,n] * (acc - rowvec[m]): softmax backward with the row term
                                 sum_j dP_ij P_ij = dctx_i . ctx_i precomputed (activations.py:32-45, attentions.py:150-155) */
+    NPM_EPI_ROWDOT = 128     /* C = acc (stored as is) AND rowdot[(n / 128) * m_total + i] += rowdot_scale * sum over the 128 columns
+                                j of column block n / 128 of C[i, j] * aux[i, j]: the row term delta_i = dctx_i . ctx_i of the attention
+                                backward (attentions.py:150-155, the Jacobian-vector product of Softmax.backward) per head of size
+                                128, taken where dctx = dy wo is produced (attentions.py:136) instead of by a pass over dctx and
+                                ctx.  `rowdot` ([n / 128, m]) must be ZERO on entry (two partial sums per element are added with
+                                float atomics: commutative, so bitwise reproducible).  Plain product only: no other epilogue flag,
+                                no batch, no split-K, n % 128 == 0, the LDS-DMA kernel's alignment rules; else NPM_E_UNSUPPORTED. */
 };
 
 typedef struct npm_gemm {
@@ -110,6 +117,7 @@ typedef struct npm_gemm {
     float *asum;                         /* optional [m]: asum[i] = sum over k of A[k, i] for a transposed A (trans_a = 1,
                                             stored [k, m]): the same for products written dproj^T x, whose bias gradient
                                             sums the FIRST operand (attentions.py:167-197).  Not together with bsum. */
+    float *rowdot; float rowdot_scale;   /* NPM_EPI_ROWDOT (ABI version 2) */
 } npm_gemm;
 
 int npm_sgemm(const npm_gemm *g);
@@ -123,7 +131,7 @@ enum {
     NPM_TUNE_GEMM_BUF_EPILOGUE = 3,
     NPM_TUNE_CONV_DMA = 4,
     NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never (default), 1 always, 2 NN / NT, 3 NT only */
-    NPM_TUNE_LN_BWD_BLOCKS = 6,      /* blocks per CU of the LayerNorm backward grid (default 4) */
+    NPM_TUNE_LN_BWD_BLOCKS = 6,      /* LayerNorm backward grid: n > 0 blocks of 4 waves per CU (rounds 1-4: 4); n < 0 |n| blocks of 12 waves per CU where the row width allows (default -1: a quarter of the partial rows, one column-sum launch behind the kernel instead of two) */
     NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
     NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, 6 / 9 / 12 several generations of shorter K ranges (measured at C3: 14.44 -> 14.6-15.0 ms), -1 unbalanced ceil(3 CUs / tiles) */
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */
@@ -136,7 +144,7 @@ enum {
     NPM_TUNE_ATTN_FWD8 = 17,         /* attention forward: 2 mha_fwd8_kernel (8 waves per block on the 16x16x4 MFMA, four waves per SIMD) for every head size; 1 below head size 128 only; 0 the 4-wave 32x32x2 mha_fwd_kernel always */
     NPM_TUNE_GEMM_SPLIT_GENS = 18,   /* split-K of tall-K products (weight gradients): 1 (default) for A-heavy products that also sum A's columns, a K range longer than 768 K tiles is cut further when that makes whole generations of resident blocks (3 x 4 per CU: the packed q/k/v weight gradient 6.00 -> 5.71 ms); 0 one generation of three blocks per CU always (round 3) */
     NPM_TUNE_STREAM_NT = 12,         /* 1 (default): the HBM-bound kernels move tensors of >= 32 MB with the nontemporal cache hint; 0: default policy */
-    NPM_TUNE_LN_NT_SPLIT = 19,       /* LayerNorm at d in (512, 1024]: backward mode + 4 * forward mode; a mode: 0 nontemporal hint on loads and stores, 1 on the loads only, 2 on the stores only.  Default 1 (backward: its dx is read at once by the GEMM behind it; measured inside the encoder step, profiles/r05_ln_nt_split.log) */
+    NPM_TUNE_LN_NT_SPLIT = 19,       /* LayerNorm at d in (512, 1024]: backward mode + 4 * forward mode; a mode: 0 nontemporal hint on loads and stores, 1 on the loads only, 2 on the stores only.  Default 5: loads only in both (dx and z are read at once by the GEMMs behind them; measured inside the encoder step, profiles/r05_ln_nt_split.log) */
     NPM_TUNE_GEMM_ABLATE = 99
 };
 int npm_set_tuning(int knob, int value);
@@ -270,6 +278,10 @@ typedef struct npm_mha_core {
     int64_t summary_all_offset;   /* bytes from a tile's "some position allowed" byte to its "every position allowed" byte (the second
                                      half of what npm_mha_mask_summary writes: planes_b * planes_h * tiles bytes later); 0 = not given.
                                      Tiles whose every position is allowed run without reading the mask. */
+    /* Optional, backward, head_dim 128: the row terms MINUS scale * (dctx_i . ctx_i) already computed by the caller (the
+     * NPM_EPI_ROWDOT epilogue of the GEMM that produced dctx), element (b, h, i) at neg_delta[b * stride_b + h * stride_h + i];
+     * npm_mha_core_bwd then does not read dctx and ctx for them.  Ignored by the kernels that do not take padded row terms. */
+    const float *neg_delta; int64_t neg_delta_stride_b, neg_delta_stride_h;
 } npm_mha_core;
 int npm_mha_core_supported(int head_dim);          /* 1 when npm_mha_core_fwd/bwd take this head dimension */
 int npm_mha_core_fwd(const npm_mha_core *c);

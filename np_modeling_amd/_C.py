@@ -18,7 +18,11 @@ RCCL_LIB_PATH = os.path.join(LIB_DIR, 'libnpm_rccl.so')
 
 
 class NpmError(RuntimeError):
-    """A C-ABI call returned non-zero."""
+    """A C-ABI call returned non-zero (``code``: the NPM_E_* / HIP / RCCL value, None for host-side errors)."""
+
+    def __init__(self, message: str, code=None):
+        super().__init__(message)
+        self.code = code
 
 
 class npm_gemm(C.Structure):
@@ -39,6 +43,7 @@ class npm_gemm(C.Structure):
         ('colsum', C.c_void_p),
         ('bsum', C.c_void_p),
         ('asum', C.c_void_p),
+        ('rowdot', C.c_void_p), ('rowdot_scale', C.c_float),
     ]
 
 
@@ -69,6 +74,7 @@ class npm_mha_core(C.Structure):
         ('dv', C.c_void_p), ('dv_pitch', C.c_int64),
         ('tile_summary', C.c_void_p), ('summary_stride_b', C.c_int64), ('summary_stride_h', C.c_int64),
         ('summary_all_offset', C.c_int64),
+        ('neg_delta', C.c_void_p), ('neg_delta_stride_b', C.c_int64), ('neg_delta_stride_h', C.c_int64),
     ]
 
 
@@ -78,7 +84,7 @@ class npm_comm_exchange_stats(C.Structure):
                 ('dropped', C.c_int)]
 
 
-EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK, EPI_RELU, EPI_SOFTMAX_BWD = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_RESIDUAL, EPI_RELU_SAVE, EPI_RELU_MASK, EPI_RELU, EPI_SOFTMAX_BWD, EPI_ROWDOT = 1, 2, 4, 8, 16, 32, 128
 
 _P, _SZ, _I64, _I32, _F = C.c_void_p, C.c_size_t, C.c_int64, C.c_int32, C.c_float
 
@@ -347,7 +353,7 @@ def comm_lib():
 def check(rc: int, what: str = '') -> None:
     if rc != 0:
         msg = _LIB.npm_last_error() if _LIB is not None else b''
-        raise NpmError(f'{what or "npm call"} failed ({rc}): {msg.decode() if msg else ""}')
+        raise NpmError(f'{what or "npm call"} failed ({rc}): {msg.decode() if msg else ""}', rc)
 
 
 def check_comm(rc: int, what: str = '') -> None:

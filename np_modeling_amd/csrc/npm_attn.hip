@@ -38,7 +38,10 @@ struct MhaArgs {
     float *ctx;
     long ctx_pitch;
     float *lse;                       // [B, H, Sq]
-    float *delta;                     // backward scratch [B, H, Sq]: rowsum(dctx * ctx) ([B, H, sq_pad] for mha_bwd8_kernel)
+    float *delta;                     // backward scratch [B, H, Sq]: rowsum(dctx * ctx); for mha_bwd16_kernel / mha_bwd8_kernel: MINUS scale *
+                                      // that, row (b, h, i) at delta[b delta_sb + h delta_sh + i], delta_len valid floats per (b, h)
+    long delta_sb, delta_sh;          //   (own scratch: [B, H, sq_pad]; the caller's npm_mha_core.neg_delta: its strides)
+    int delta_len;
     float *lse2;                      // mha_bwd8_kernel: [B, H, sq_pad] log2(e) * LSE, zeros in the padding
     int sq_pad;                       // seq_q rounded up to whole 32-query tiles
     const unsigned char *skip;        // optional tile summary (npm_mha_mask_summary): byte (qt, kb) at skip[b sb + h sh + qt nkb + kb]
@@ -1195,7 +1198,7 @@ mha_bwd16_kernel(const MhaArgs p) {
     // row terms (mha_rowterms_kernel): log2(e) LSE and MINUS delta, padded to whole tiles and finite in the padding, so that a
     // lane's four consecutive queries are one 16-byte load each -- no staging through LDS, no multiply, no exec-masked writes
     const auto rsrcL = make_rsrc(p.lse2 + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
-    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
+    const auto rsrcDl = make_rsrc(p.delta + b * p.delta_sb + h * p.delta_sh, (long)p.delta_len * 4);
     const auto rsrcS = make_rsrc(p.scores + (long)bh * p.seq_q * p.seq_kv, (long)p.seq_q * p.seq_kv * 4);
     const int srow_bytes = p.seq_kv * 4;
 
@@ -1515,7 +1518,7 @@ mha_bwd8_kernel(const MhaArgs p) {
     const auto rsrcNone = make_rsrc(p.dq, 0);
     // row terms, padded to whole tiles and finite in the padding (mha_rowterms_kernel): no straddling 16-byte load
     const auto rsrcL = make_rsrc(p.lse2 + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
-    const auto rsrcDl = make_rsrc(p.delta + (long)bh * p.sq_pad, (long)p.sq_pad * 4);
+    const auto rsrcDl = make_rsrc(p.delta + b * p.delta_sb + h * p.delta_sh, (long)p.delta_len * 4);
     const auto rsrcS = make_rsrc(SAVED ? p.scores + (long)bh * p.seq_q * p.seq_kv : nullptr, SAVED ? (long)p.seq_q * p.seq_kv * 4 : 0);
     const int srow_bytes = p.seq_kv * 4;
     const auto rsrcM = make_rsrc(MASK ? p.mask + b * p.mask_sb + h * p.mask_sh : nullptr, MASK ? (long)(p.seq_q - 1) * p.mask_sq + p.seq_kv : 0);
@@ -1969,6 +1972,15 @@ mha_rowterms_kernel(const float *__restrict__ dctx, long dctx_pitch, const float
     }
 }
 
+// lse2 alone (the caller brought the delta row terms: npm_mha_core.neg_delta): [B, H, sq_pad] = log2(e) * LSE, zeros in the padding
+__global__ void __launch_bounds__(256)
+mha_lse2_kernel(const float *__restrict__ lse, float *__restrict__ lse2, long planes, long seq, long sq_pad) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= planes * sq_pad) return;
+    const long bh = i / sq_pad, s_ = i - bh * sq_pad;
+    lse2[i] = s_ < seq ? lse[bh * seq + s_] * LOG2E : 0.f;
+}
+
 // Tile summary of a mask: byte (qt, kb) of plane (b, h) has bit w set when some position of queries 32 qt .. 32 qt + 31 x keys
 // 128 kb + 16 w .. + 15 is allowed; a second array of the same shape behind it (`total` bytes later) has the bit set when EVERY
 // position of the sub-tile that lies inside the tensors is.  One block per (plane, qt, kb): thread = (query row, 16-key group).
@@ -2225,12 +2237,24 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
         const long padded = (long)a.batch * a.heads * a.sq_pad;
         rc = ws.alloc(sizeof(float) * 2 * (size_t)padded);
         if (rc) return rc;
-        a.delta = (float *)ws.ptr;
-        a.lse2 = a.delta + padded;
-        NPM_ARG((padded * 32 + 255) / 256 < (1L << 31));
-        hipLaunchKernelGGL(mha_rowterms_kernel, dim3((int)((padded * 32 + 255) / 256)), dim3(256), 0, s, a.dctx, a.dctx_pitch,
-                           (const float *)a.ctx, a.ctx_pitch, (const float *)a.lse, a.delta, a.lse2, (long)a.batch, (long)a.seq_q,
-                           (long)a.sq_pad, a.heads, c->head_dim, a.scale);
+        a.lse2 = (float *)ws.ptr + padded;
+        if (c->neg_delta != nullptr) {
+            // the caller computed MINUS scale * (dctx_i . ctx_i) where dctx was produced (NPM_EPI_ROWDOT): no pass over dctx and ctx
+            NPM_ARG(c->neg_delta_stride_b >= 0 && c->neg_delta_stride_h >= 0 && al16(c->neg_delta) &&
+                    c->neg_delta_stride_b % 4 == 0 && c->neg_delta_stride_h % 4 == 0);
+            a.delta = const_cast<float *>(c->neg_delta);
+            a.delta_sb = c->neg_delta_stride_b; a.delta_sh = c->neg_delta_stride_h; a.delta_len = a.seq_q;
+            NPM_ARG((padded + 255) / 256 < (1L << 31));
+            hipLaunchKernelGGL(mha_lse2_kernel, dim3((int)((padded + 255) / 256)), dim3(256), 0, s, (const float *)a.lse, a.lse2,
+                               (long)a.batch * a.heads, (long)a.seq_q, (long)a.sq_pad);
+        } else {
+            a.delta = (float *)ws.ptr;
+            a.delta_sb = (long)a.heads * a.sq_pad; a.delta_sh = a.sq_pad; a.delta_len = a.sq_pad;
+            NPM_ARG((padded * 32 + 255) / 256 < (1L << 31));
+            hipLaunchKernelGGL(mha_rowterms_kernel, dim3((int)((padded * 32 + 255) / 256)), dim3(256), 0, s, a.dctx, a.dctx_pitch,
+                               (const float *)a.ctx, a.ctx_pitch, (const float *)a.lse, a.delta, a.lse2, (long)a.batch, (long)a.seq_q,
+                               (long)a.sq_pad, a.heads, c->head_dim, a.scale);
+        }
         NPM_CHECK_LAUNCH();
         npm::note_math(NPM_MATH_F32);
         if (use16) {

@@ -164,9 +164,10 @@ sgemm_mfma_kernel(const GemmArgs p) {
 // the same B (A) tile split its 16 k rows between them, so every block carries the same small load (a launch of
 // co-resident blocks lasts as long as its slowest block): one or two LDS reads and adds per thread and K tile.
 // Partial sums: one row per (split, sharing block); the host adds the rows.
-template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2, int KSUM = 0, int MATH = 0>
+template <bool A_KMAJ, bool B_KMAJ, bool WITH_COLSUM, int WM = 2, int WN = 2, int KSUM = 0, int MATH = 0, bool ROWDOT = false>
 __global__ void __launch_bounds__(64 * WM * WN, (MATH == 2 ? 8 : (WITH_COLSUM || MATH) ? 12 : 16) / (WM * WN))   // 16 (12, 8) waves per CU
 sgemm_glds_kernel(const GemmArgs p) {
+    static_assert(!ROWDOT || (WM == 2 && WN == 2 && !WITH_COLSUM && !KSUM && !MATH), "ROWDOT: the plain 128 x 128 exact-fp32 instance");
     static_assert(!KSUM || (!A_KMAJ && !B_KMAJ && WM == 2 && WN == 2 && !WITH_COLSUM), "KSUM: TN layout, 128 x 128 tile");
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int A_TILE = TM * GK, B_TILE = TN * GK, STAGE = A_TILE + B_TILE;
@@ -333,7 +334,7 @@ sgemm_glds_kernel(const GemmArgs p) {
         return;
     }
     Epilogue e = p.e;
-    if (p.splits > 1) {
+    if (!ROWDOT && p.splits > 1) {
         e.ws += (long)split * p.slab + (long)z * p.M * p.N;
         if (e.buf_ok) write_tile_buf(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
         else write_tile(acc, e, true, m0, n0, p.M, p.N, wm, wn, l32, half);
@@ -349,6 +350,10 @@ sgemm_glds_kernel(const GemmArgs p) {
         e.cs += (((long)(z0 * p.tiles_m + tm) * 2) * nb1 + z1) * p.N;
         e.cs_wm = (long)nb1 * p.N;
         write_tile_buf<true>(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
+        return;
+    }
+    if (ROWDOT) {                // NPM_EPI_ROWDOT (the host admits it only where the buffer epilogue runs)
+        write_tile_buf<false, true>(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
         return;
     }
     if (e.buf_ok) write_tile_buf(acc, e, false, m0, n0, p.M, p.N, wm, wn, l32, half);
@@ -385,7 +390,10 @@ void launch(const GemmArgs &a, bool vec, bool dma, int grid, hipStream_t stream)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false, 2, 4>), dim3(grid), dim3(512), 0, stream, a);
     else if (dma && a.e.cs)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
-    else if (dma)
+    else if (dma && a.e.rowdot) {
+        if constexpr (A_KMAJ && !B_KMAJ)       // dctx = dy wo (attentions.py:136): the one product that takes it
+            hipLaunchKernelGGL((sgemm_glds_kernel<true, false, false, 2, 2, 0, 0, true>), dim3(grid), dim3(NTHREADS), 0, stream, a);
+    } else if (dma)
         hipLaunchKernelGGL((sgemm_glds_kernel<A_KMAJ, B_KMAJ, false>), dim3(grid), dim3(NTHREADS), 0, stream, a);
     else if (!vec)
         hipLaunchKernelGGL((sgemm_mfma_kernel<A_KMAJ, B_KMAJ, false, 0>), dim3(grid), dim3(NTHREADS), 0, stream, a);
@@ -483,6 +491,8 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     NPM_ARG(!((epi & NPM_EPI_RELU_SAVE) && (epi & NPM_EPI_RELU_MASK)));
     NPM_ARG(!(epi & NPM_EPI_SOFTMAX_BWD) || (g->aux != nullptr && g->rowvec != nullptr &&
             !(epi & (NPM_EPI_RESIDUAL | NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_BIAS))));
+    const bool rowdot = (epi & NPM_EPI_ROWDOT) != 0;
+    NPM_ARG(!rowdot || (epi == NPM_EPI_ROWDOT && g->aux != nullptr && g->rowdot != nullptr && g->alpha == 1.f));
 
     const bool a_kmaj = g->trans_a == 0;   // A[M,K]: K contiguous
     const bool b_kmaj = g->trans_b != 0;   // B stored [N,K]: K contiguous
@@ -520,14 +530,17 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     a.e.bias = g->bias;
     a.e.R = (epi & NPM_EPI_RESIDUAL) ? g->residual : nullptr;
     a.e.ldr = g->ldr;
-    a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD)) ? g->aux : nullptr;
+    a.e.aux = (epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD | NPM_EPI_ROWDOT)) ? g->aux : nullptr;
+    a.e.rowdot = rowdot ? g->rowdot : nullptr;
+    a.e.rowdot_scale = g->rowdot_scale;
+    a.e.rowdot_m = g->m;
     a.e.rowvec = (epi & NPM_EPI_SOFTMAX_BWD) ? g->rowvec : nullptr;
     a.e.ldaux = g->ldaux;
     {
         // the buffer epilogue addresses one block (<= 256 rows) at a time: its row pitches must keep that below 2^31
         auto fits = [&](long ld) { return (256L * ld + g->n) * 4 < (1L << 31); };
         a.e.buf_ok = g_buf_epilogue && fits(g->ldc) && (!(epi & NPM_EPI_RESIDUAL) || fits(g->ldr)) &&
-                     (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD)) || fits(g->ldaux)) && fits(g->n);
+                     (!(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_SOFTMAX_BWD | NPM_EPI_ROWDOT)) || fits(g->ldaux)) && fits(g->n);
     }
     a.group_m = g_group_m;
     a.ablate = g_ablate;
@@ -541,7 +554,7 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     // Split-K: only for the linear epilogues, when the grid cannot fill 256 CUs x 2-3 blocks.
     int splits = 1;
     const int nkt = (g->k + BK - 1) / BK;
-    const bool linear_epi = !(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_RELU | NPM_EPI_SOFTMAX_BWD));
+    const bool linear_epi = !(epi & (NPM_EPI_RELU_SAVE | NPM_EPI_RELU_MASK | NPM_EPI_RELU | NPM_EPI_SOFTMAX_BWD | NPM_EPI_ROWDOT));
     if (g->split_k > 1) {
         splits = g->split_k;
     } else if (g->split_k == 0 && linear_epi && tiles < 2L * npm::ctx().num_cus && nkt >= 16) {
@@ -580,6 +593,9 @@ extern "C" int npm_sgemm(const npm_gemm *g) {
     if (a.wide && !(dma && a.e.buf_ok))
         return npm::fail(NPM_E_UNSUPPORTED, "npm_sgemm: operand spans too large for the 128x256 tile (disable NPM_TUNE_GEMM_WIDE_TILE)");
     const bool dma_path = dma && a.e.buf_ok;
+    if (rowdot && !(dma_path && a_kmaj && !b_kmaj && !a.wide && batch == 1 && splits == 1 && g->n % 128 == 0 && g_math == 0 && !a.ablate && !a.trace))
+        return npm::fail(NPM_E_UNSUPPORTED, "npm_sgemm: NPM_EPI_ROWDOT needs the 128 x 128 LDS-DMA kernel in exact fp32 (A [M, K], B [K, N], "
+                                            "aligned operands, k %% 16 == 0, n %% 128 == 0, no batch, no split-K)");
     // Column sums of B beside a TN product: in the kernel when the LDS-DMA path runs, else a pass over B.
     npm::Scratch bs_part;
     // NPM_MATH_F16X2: one product (no batch), the LDS-DMA path's alignment rules, no epilogue column sums

@@ -33,6 +33,9 @@ struct Epilogue {
     float *cs;               // optional column-sum partials: one row of N per (tile row, wave row)
     long cs_wm;              // elements between the partial rows of wave rows wm = 0 and 1
     int prio;                // NPM_TUNE_GEMM_WAVE_PRIO: bit 0 raise the wave's issue priority in the prologue, bit 1 in the epilogue
+    float *rowdot;           // NPM_EPI_ROWDOT: [N / 128][M] row dots of C with aux per 128-column block (zero on entry)
+    float rowdot_scale;
+    long rowdot_m;           // M: elements between the rows of two column blocks
 };
 
 // Wave issue priority (s_setprio).  Three of the four blocks of a CU are always inside their MFMA loops; the
@@ -255,12 +258,67 @@ __device__ __forceinline__ void rmw_epilogue(const f32x16 (&acc)[2][2], const Ep
     }
 }
 
+// NPM_EPI_ROWDOT: store the accumulators as they are and add, per row, scale * sum_j acc[row, j] * aux[row, j] over this wave's 64
+// columns to rowdot[column block][row] (the other wave of the tile row adds its 64: two commutative float atomics onto zero).
+// Lane layout of a 32 x 32 MFMA result: column l32 on the lane, rows (r & 3) + 8 (r >> 2) + 4 half in registers r.  Per row
+// tile i the 16 per-lane products (both column tiles added) are summed over the 32 lanes of a half: one exchange with lane ^ 16
+// that adds all 16, then a transposing butterfly (step m = 8, 4, 2, 1: a lane keeps the half of its values whose index has bit
+// m equal to its own lane bit and sends the other half to lane ^ m), after which lane l32 holds the sum of register
+// r = l32 & 15.  31 exchanges per row tile, all ds_bpermute (LDS pipe): beside three co-resident blocks of back-to-back MFMAs
+// it is VECTOR-ALU instructions that cost.  One row tile at a time: 16 sums + 16 aux values live beside the 64 accumulators
+// (the kernel keeps its 128 registers = four blocks per CU).
+__device__ __forceinline__ void rowdot_epilogue(const f32x16 (&acc)[2][2], const Epilogue &e, __amdgpu_buffer_rsrc_t rc, const int (&vc)[2],
+                                                int ldc, int row0, int rows_here, int m0, int n0, int N, int wn, int l32, int half) {
+    constexpr int OOB = 0x7FFFFFFF;
+    const int ldx = (int)e.ldaux;
+    const auto rx = __builtin_amdgcn_make_buffer_rsrc((void *)(e.aux + (long)m0 * ldx), 0, (int)(((long)(rows_here - 1) * ldx + N) * 4), 0x00020000);
+    const int lane = 32 * half + l32;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l32;
+            const int vx = col < N ? (4 * half * ldx + col) * 4 : OOB;
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {            // eight aux values at a time: the register file is full
+                float x[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    const int r = 8 * q + t;
+                    const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2);
+                    x[t] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rx, vx, row * ldx * 4, 0));
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][r]), rc, vc[j], row * ldc * 4, 0);
+                }
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[8 * q + t] = j == 0 ? acc[i][0][8 * q + t] * x[t] : fmaf(acc[i][1][8 * q + t], x[t], v[8 * q + t]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            v[r] += __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 16) << 2, __builtin_bit_cast(int, v[r])));
+#pragma unroll
+        for (int m = 8, n = 16; m >= 1; m >>= 1, n >>= 1) {
+            const bool upper = (l32 & m) != 0;
+#pragma unroll
+            for (int k = 0; k < n / 2; ++k) {
+                const float keep = upper ? v[k + n / 2] : v[k], send = upper ? v[k] : v[k + n / 2];
+                v[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ m) << 2, __builtin_bit_cast(int, send)));
+            }
+        }
+        const int r = l32 & 15;
+        const int row = row0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (l32 < 16 && row < rows_here) atomicAdd(e.rowdot + (long)(n0 / 128) * e.rowdot_m + m0 + row, e.rowdot_scale * v[0]);
+    }
+}
+
 // Branch-free epilogue through buffer instructions.  Each store is ONE instruction:
 // the per-lane column offset sits in the VGPR offset (computed once), the row offset is a
 // scalar (soffset) and rows >= M / columns >= N are dropped by the descriptor's range check
 // (out-of-range lanes carry an offset beyond num_records) -- no per-element address VALU,
 // no exec-mask juggling.  Requires every extent below 2^31 bytes (the host checks).
-template <bool WITH_COLSUM = false>
+template <bool WITH_COLSUM = false, bool ROWDOT = false>
 __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const Epilogue &e, bool raw,
                                                int m0, int n0, int M, int N, int wm, int wn, int l32, int half) {
     constexpr int OOB = 0x7FFFFFFF;
@@ -289,6 +347,10 @@ __device__ __forceinline__ void write_tile_buf(const f32x16 (&acc)[2][2], const 
     }
     const int row0 = wm * 64;                          // wave-uniform, relative to the block's first row
 
+    if constexpr (ROWDOT) {        // its own kernel instantiation: the other epilogues carry none of this
+        rowdot_epilogue(acc, e, rc, vc, ldc, row0, rows_here, m0, n0, N, wn, l32, half);
+        return;
+    }
     if (!has_res && !relu_save && !relu_mask && !sm_bwd) {
         // Store-only epilogues (plain, bias, relu): 64 stores back to back, nothing to wait for.  Vector-ALU
         // instructions of an epilogue issue slowly beside three blocks of back-to-back MFMAs (measured: 64 raw

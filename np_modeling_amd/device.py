@@ -610,6 +610,9 @@ def attn_save_scores(head_size: int) -> bool:
 
 # masked attention: let the fused kernels skip tiles without an allowed position (NPM_ATTN_TILE_SKIP=0: visit them all)
 ATTN_TILE_SKIP = os.environ.get('NPM_ATTN_TILE_SKIP', '1') != '0'
+# head size 128: the attention backward's row terms (dctx . ctx per query and head) come out of the epilogue of the GEMM that
+# produces dctx (NPM_EPI_ROWDOT) instead of a pass over dctx and ctx in front of the attention kernel (NPM_ATTN_ROWDOT=0: that pass)
+ATTN_ROWDOT = os.environ.get('NPM_ATTN_ROWDOT', '1') != '0'
 
 class KernelTimer:
     """Brackets every kernel-wrapper call with HIP events on the compute stream and books its
@@ -675,8 +678,11 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
          residual: Optional[Mat] = None, relu_save: Optional[Mat] = None, relu_mask: Optional[Mat] = None,
          split_k: int = 0, colsum_out: Optional[DeviceArray] = None,
          softmax_bwd: Optional[Tuple[Mat, DeviceArray]] = None,
-         bsum_out: Optional[DeviceArray] = None, asum_out: Optional[DeviceArray] = None) -> None:
+         bsum_out: Optional[DeviceArray] = None, asum_out: Optional[DeviceArray] = None,
+         rowdot: Optional[Tuple[Mat, DeviceArray, float]] = None) -> None:
     """C = epilogue(alpha * op(A) @ op(B)); see include/npm_hip.h ``npm_sgemm``.
+    ``rowdot=(X, out, scale)``: besides C = A @ B, out[n // 128, m] (zeros on entry) += scale * sum over each block of 128
+    columns of C * X -- the attention backward's row term dctx . ctx per head of size 128, taken where dctx is produced.
     ``colsum_out`` ([batch1, n]) receives the column sums of the stored C (a bias gradient
     taken in the producing GEMM's epilogue instead of a separate pass over C).
     ``softmax_bwd=(P, delta)``: C = alpha * P * (A @ B - delta[row]) -- the softmax backward with its
@@ -709,6 +715,10 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
         epi |= _C.EPI_SOFTMAX_BWD
         g.aux, g.ldaux = softmax_bwd[0].ptr, softmax_bwd[0].ld
         g.rowvec = softmax_bwd[1].ptr
+    if rowdot is not None:
+        epi |= _C.EPI_ROWDOT
+        g.aux, g.ldaux = rowdot[0].ptr, rowdot[0].ld
+        g.rowdot, g.rowdot_scale = rowdot[1].ptr, float(rowdot[2])
     g.epilogue = epi
     g.split_k = int(split_k)
     fuse = colsum_out is not None and FUSE_COLSUM
@@ -720,7 +730,7 @@ def gemm(m: int, n: int, k: int, a: Mat, b: Mat, c: Mat, *, trans_a: bool = Fals
     layout = 'TN' if trans_a else ('NT' if trans_b else 'NN')
     nb = batch[0] * batch[1]
     unique = 4.0 * nb * (m * k + k * n + m * n * (1 + (residual is not None) + (relu_save is not None) +
-                                                  (relu_mask is not None) + (softmax_bwd is not None)))
+                                                  (relu_mask is not None) + (softmax_bwd is not None) + (rowdot is not None)))
     with _timed('sgemm_' + layout, flops=2.0 * m * n * k * nb, nbytes=unique):
         _C.check(_C.lib().npm_sgemm(C.byref(g)), 'npm_sgemm')
     if bsum_out is not None and not fuse_b:      # A/B switch: separate pass over B
@@ -916,13 +926,16 @@ def mha_core_fwd(q: Mat, k: Mat, v: Mat, dims, scale: float, mask: Optional[Attn
 
 def mha_core_bwd(q: Mat, k: Mat, v: Mat, ctx: DeviceArray, lse: DeviceArray, dctx: DeviceArray,
                  dq: Mat, dk: Mat, dv: Mat, dims, scale: float, mask: Optional[AttnMask] = None,
-                 scores: Optional[DeviceArray] = None) -> None:
+                 scores: Optional[DeviceArray] = None, neg_delta: Optional[Tuple[DeviceArray, int, int]] = None) -> None:
     """dq, dk, dv of the attention core from q, k, v, the forward's ctx and lse, and dctx (npm_mha_core_bwd).
-    Algorithmic work: the four products dP, dV, dK, dQ (the recomputed q.k is the kernel's own business)."""
+    Algorithmic work: the four products dP, dV, dK, dQ (the recomputed q.k is the kernel's own business).
+    ``neg_delta=(array, stride_b, stride_h)``: the row terms -scale * (dctx . ctx) already taken by the GEMM that produced dctx."""
     b, h, sq, skv, d = dims
     c = _core_desc(q, k, v, Mat(ctx, h * d), lse, dims, scale, mask, scores)
     c.dctx, c.dctx_pitch = dctx.ptr, h * d
     c.dq, c.dq_pitch, c.dk, c.dk_pitch, c.dv, c.dv_pitch = dq.ptr, dq.ld, dk.ptr, dk.ld, dv.ptr, dv.ld
+    if neg_delta is not None:
+        c.neg_delta, c.neg_delta_stride_b, c.neg_delta_stride_h = neg_delta[0].ptr, int(neg_delta[1]), int(neg_delta[2])
     nbytes = 4.0 * b * h * d * (4 * sq + 4 * skv) + (4.0 * b * h * sq * skv if scores is not None else 0.0)
     with _timed('mha_core_bwd', flops=8.0 * b * h * sq * skv * d, nbytes=nbytes):
         _C.check(_C.lib().npm_mha_core_bwd(C.byref(c)), 'npm_mha_core_bwd')

@@ -217,7 +217,21 @@ class MultiHeadAttention(layer.StatefulLayer):
         dwo = scope.take(wo.shape, owner=(self, '_wo'))
         D.gemm(f, h * dv, m_q, Mat(dy, f), Mat(ctx, h * dv), Mat(dwo, h * dv), trans_a=True, asum_out=dbo)   # dy^T ctx
         dctx = D.empty([b, sq, h, dv])
-        D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))                    # dy wo
+        # dy wo.  At head size 128 a column block of that GEMM's tiles IS a head: its epilogue also takes the row terms
+        # -scale * (dctx_i . ctx_i) the fused backward needs (the Jacobian-vector product of Softmax.backward,
+        # activations.py:42-45 / attentions.py:150-155), [H, B * Sq], instead of a pass over dctx and ctx behind it.
+        neg_delta = None
+        if self._core and dv == 128 and D.ATTN_ROWDOT and D.attn_save_scores(dk) and f % 16 == 0 and sq % 4 == 0 \
+                and D._C.current_math() == 'f32':
+            rows = D.zeros([h, m_q])
+            try:
+                D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv), rowdot=(Mat(ctx, h * dv), rows, -self._scale))
+                neg_delta = (rows, sq, m_q)
+            except D._C.NpmError as err:                   # operands the row-dot instance does not take (alignment): the plain product
+                if err.code != 10003:
+                    raise
+        if neg_delta is None:
+            D.gemm(m_q, h * dv, f, Mat(dy, f), Mat(wo, h * dv), Mat(dctx, h * dv))
 
         packed = self._packed
         pq, pk, pv = self._pitches
@@ -238,7 +252,7 @@ class MultiHeadAttention(layer.StatefulLayer):
         if self._core:
             # attentions.py:146-162 in one kernel: P is recomputed from the saved log-sum-exp, tile by tile
             D.mha_core_bwd(Mat(q, pq), Mat(k, pk), Mat(v, pv), ctx, self._lse, dctx, Mat(dq, gq), Mat(dk_, gk),
-                           Mat(dv_, gv), (b, h, sq, skv, dk), self._scale, self._mask, self._raw_scores)
+                           Mat(dv_, gv), (b, h, sq, skv, dk), self._scale, self._mask, self._raw_scores, neg_delta=neg_delta)
         else:
             # softmax @ V (attentions.py:146-148)
             # dP = dctx_h v_h^T followed by the softmax backward and the 1/sqrt(dk) of attentions.py:150-155.

@@ -144,6 +144,13 @@ class HostSim:
                 if g.epilogue & 16:
                     v = np.maximum(v, 0.0)
                 _mat(g.c + oc, g.m, g.n, g.ldc)[:] = v
+                if g.epilogue & 128:                     # NPM_EPI_ROWDOT: per block of 128 columns, row dots of C with aux, added to zeros
+                    if g.epilogue != 128 or g.trans_a or g.trans_b or g.n % 128 or g.k % 16 or g.batch0 * g.batch1 != 1:
+                        return 10003
+                    prod = _mat(g.c + oc, g.m, g.n, g.ldc).astype(np.float64) * _mat(g.aux + oc, g.m, g.n, g.ldaux).astype(np.float64)
+                    out = _vec(g.rowdot, (g.n // 128) * g.m).reshape(g.n // 128, g.m)
+                    assert not np.isnan(out).any() and (out == 0).all(), 'NPM_EPI_ROWDOT: rowdot must be zero on entry'
+                    out += (np.float64(g.rowdot_scale) * prod.reshape(g.m, g.n // 128, 128).sum(axis=2).T).astype(np.float32)
                 sums[z1] += _mat(g.c + oc, g.m, g.n, g.ldc).astype(np.float64).sum(axis=0)
         if g.colsum:
             _vec(g.colsum, g.batch1 * g.n)[:] = sums.ravel()
@@ -301,6 +308,13 @@ class HostSim:
         if mask is not None:
             scaled = np.where(mask, scaled, -np.inf)
         probs = np.exp(scaled - lse[..., None])             # from the saved log-sum-exp, as the kernel does
+        if c.neg_delta:                                     # the caller's row terms: what the kernel would have computed itself
+            ctx = self._heads(c.ctx, c.ctx_pitch, b, sq, h, d).astype(np.float64)
+            want = -float(c.scale) * np.einsum('bqhd,bqhd->bhq', dctx, ctx)
+            extent = (b - 1) * c.neg_delta_stride_b + (h - 1) * c.neg_delta_stride_h + sq
+            got = np.lib.stride_tricks.as_strided(_vec(c.neg_delta, extent), shape=(b, h, sq),
+                                                  strides=(4 * c.neg_delta_stride_b, 4 * c.neg_delta_stride_h, 4))
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * (np.abs(want).max() + 1e-30), err_msg='neg_delta')
         dq, dk, dv = O.attention_core_bwd(q, k, v, probs, dctx, float(c.scale))
         self._heads(c.dq, c.dq_pitch, b, sq, h, d)[:] = dq
         self._heads(c.dk, c.dk_pitch, b, skv, h, d)[:] = dk

@@ -74,7 +74,9 @@ def test_struct_layouts_match_header(built):
             'offsetof(npm_comm_exchange_stats, exposed_ms), offsetof(npm_comm_exchange_stats, last_allreduce_ms), '
             'offsetof(npm_comm_exchange_stats, dropped));'
             'printf("%zu %zu %zu %zu %zu %d\\n", sizeof(npm_mha_core), offsetof(npm_mha_core, mask), offsetof(npm_mha_core, dctx), '
-            'offsetof(npm_mha_core, tile_summary), offsetof(npm_mha_core, summary_all_offset), NPM_ABI_VERSION);return 0;}\n')
+            'offsetof(npm_mha_core, tile_summary), offsetof(npm_mha_core, summary_all_offset), NPM_ABI_VERSION);'
+            'printf("%zu %zu %zu\\n", offsetof(npm_gemm, rowdot), offsetof(npm_gemm, rowdot_scale), offsetof(npm_mha_core, neg_delta_stride_h));'
+            'return 0;}\n')
     with tempfile.TemporaryDirectory() as tmp:
         src = os.path.join(tmp, 'abi.c')
         open(src, 'w').write(prog)
@@ -87,7 +89,8 @@ def test_struct_layouts_match_header(built):
             _C.npm_comm_exchange_stats.exposed_ms.offset, _C.npm_comm_exchange_stats.last_allreduce_ms.offset,
             _C.npm_comm_exchange_stats.dropped.offset,
             ctypes.sizeof(_C.npm_mha_core), _C.npm_mha_core.mask.offset, _C.npm_mha_core.dctx.offset,
-            _C.npm_mha_core.tile_summary.offset, _C.npm_mha_core.summary_all_offset.offset, 2]
+            _C.npm_mha_core.tile_summary.offset, _C.npm_mha_core.summary_all_offset.offset, 2,
+            _C.npm_gemm.rowdot.offset, _C.npm_gemm.rowdot_scale.offset, _C.npm_mha_core.neg_delta_stride_h.offset]
     assert got == want
     # every struct of the header that grew since version 1 is covered above; the ctypes mirror of npm_mha_core field by field
     assert c_fields('npm_mha_core') == [f[0] for f in _C.npm_mha_core._fields_]

@@ -477,3 +477,43 @@ def test_softmax_backward_fused_into_the_dp_gemm(D, bsz, h, sq, skv, d):
     dP = np.einsum('bqhd,bkhd->bhqk', dctx.astype(np.float64), v.astype(np.float64))
     want = scale * O.softmax_bwd(p.astype(np.float64), dP, verbatim=(sq * skv * skv < 2e6))
     assert_close(datt, want, tol=1e-5)
+
+
+@pytest.mark.parametrize('m,n,k', [(128, 128, 16), (300, 256, 64), (1000, 1024, 128), (77, 384, 48)])
+def test_rowdot_epilogue(D, m, n, k):
+    """NPM_EPI_ROWDOT: C = A B stored as is, and out[n // 128, m] += scale * the row dots of C with X per block of 128 columns --
+    the attention backward's row term dctx . ctx per head of size 128, taken where dctx = dy wo is produced (attentions.py:136,
+    150-155).  Ragged M (rows beyond M add nothing, the guard rows stay zero), two atomic adds per element onto zeros: bitwise
+    reproducible.  Exact fp32 only; any other mode, layout or shape is refused (NPM_E_UNSUPPORTED), never computed differently."""
+    from np_modeling_amd import _C
+    rng = np.random.default_rng(m + n + k)
+    a = rng.standard_normal((m, k)).astype(np.float32)
+    b = rng.standard_normal((k, n)).astype(np.float32)
+    x = rng.standard_normal((m, n)).astype(np.float32)
+    da, db, dx = D.from_host(a), D.from_host(b), D.from_host(x)
+    runs = []
+    for _ in range(2):
+        dc, out = D.full([m, n], np.nan), D.zeros([n // 128, m + 8])
+        if _C.current_math() != 'f32':
+            with pytest.raises(_C.NpmError) as err:
+                D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(dc, n), rowdot=(D.Mat(dx, n), out, -0.25))
+            assert err.value.code == 10003
+            return
+        # (out has M + 8 columns per block: the kernel is told M, so its rows are M apart -- a flat [n // 128, m] view)
+        flat = out.flat_view(0, [n // 128, m])
+        D.gemm(m, n, k, D.Mat(da, k), D.Mat(db, n), D.Mat(dc, n), rowdot=(D.Mat(dx, n), flat, -0.25))
+        runs.append((dc.numpy(), flat.numpy(), out.numpy().ravel()[(n // 128) * m:]))
+    c = _ref(a, b, False, False)
+    assert_close(runs[0][0], c, tol=2e-6)
+    want = -0.25 * (c * x.astype(np.float64)).reshape(m, n // 128, 128).sum(axis=2).T
+    assert_close(runs[0][1], want, tol=3e-6)
+    np.testing.assert_array_equal(runs[0][2], 0.0)                       # nothing written behind the last row
+    np.testing.assert_array_equal(runs[0][0], runs[1][0])
+    np.testing.assert_array_equal(runs[0][1], runs[1][1])                # two commutative adds per element: same bits every run
+    if m == 128:
+        for bad in (dict(n=192), dict(trans_b=True), dict(k=24)):
+            nn, kk = bad.get('n', n), bad.get('k', k)
+            with pytest.raises(_C.NpmError) as err:
+                D.gemm(m, nn, kk, D.Mat(da, k), D.Mat(db, n), D.Mat(D.empty([m, n]), n), trans_b=bad.get('trans_b', False),
+                       rowdot=(D.Mat(dx, n), D.zeros([2, m]), 1.0))
+            assert err.value.code == 10003, bad

@@ -322,6 +322,40 @@ def test_mha_reference_test_shape_vs_oracle(npm, math_mode):
         assert_close(getattr(layer, '_' + n), p[n] - 0.01 * grads[n], tol=1e-5, what=n)
 
 
+@pytest.mark.parametrize('rowdot', [True, False])
+@pytest.mark.parametrize('cross', [False, True])
+def test_mha_head_size_128_row_terms_from_the_dctx_gemm(npm, monkeypatch, rowdot, cross):
+    """Head size 128 (the C4 / C5 head): the attention backward's row terms come out of the epilogue of the dctx = dy wo GEMM
+    (NPM_EPI_ROWDOT) by default, or from the pass inside npm_mha_core_bwd (NPM_ATTN_ROWDOT=0); both against the oracle, self-
+    and cross-attention (Sq != Skv, ragged against the 32-query tiles)."""
+    from np_modeling_amd import _C, device as D
+    monkeypatch.setattr(D, 'ATTN_ROWDOT', rowdot)
+    np.random.seed(1)
+    layer = npm.layers.MultiHeadAttention(num_heads=2)
+    query = rand([3, 72, 256])
+    kv = rand([3, 200, 256]) if cross else None
+    args = (query, kv) if cross else (query,)
+    layer(*args)
+    p = {n: np.asarray(getattr(layer, '_' + n)).astype(np.float64) / (16.0 if n[0] == 'w' else 1.0) for n in _MHA}
+    for n in _MHA:
+        getattr(layer, '_' + n).set(p[n].astype(np.float32))
+        p[n] = p[n].astype(np.float32).astype(np.float64)
+    out = layer(*args)
+    want, cache = O.mha_fwd(p, query.astype(np.float64), None if kv is None else kv.astype(np.float64))
+    assert_close(out, want, tol=1e-5)
+    dy = rand([3, 72, 256]) * 0.01
+    calls = []
+    inner = D.gemm
+    monkeypatch.setattr(D, 'gemm', lambda *a, **k: (calls.append(k.get('rowdot') is not None), inner(*a, **k))[1])
+    dq, dk, dv = layer(dy, backprop=True, learning_rate=0.01)
+    assert any(calls) == rowdot and _C.last_attn_kernel().startswith('mha_bwd16_kernel' if not cross else 'mha_bwd')
+    (wq_, wk_, wv_), grads = O.mha_bwd(p, cache, dy.astype(np.float64))
+    assert_close(dq, wq_, tol=1e-5)
+    assert_close(np.asarray(dk) + np.asarray(dv), wk_ + wv_, tol=1e-5)
+    for n in _MHA:
+        assert_close(getattr(layer, '_' + n), p[n] - 0.01 * grads[n], tol=1e-5, what=n)
+
+
 def test_mha_deepcopy_after_packed_forward(npm):
     """attentions_test.py:72 on the PACKED self-attention path (default-initialised parameters, one q/k/v GEMM):
     the cached k and v are views into the packed buffer; a deep copy made between forward and backward must give

@@ -940,3 +940,34 @@ def test_bench_traffic_figure_belongs_to_this_build(monkeypatch):
     args.batch = 8
     assert bench.load_pmc_traffic(args)[0] is None
     assert len(_C.source_id.__wrapped__()) == 16 if hasattr(_C.source_id, '__wrapped__') else True
+
+
+def test_mha_row_terms_from_the_dctx_gemm_on_simulator(npm, monkeypatch):
+    """Head size 128: the GEMM that produces dctx = dy wo also takes -scale * (dctx . ctx) per query and head (NPM_EPI_ROWDOT,
+    [H, B * Sq]) and the fused attention backward gets it as ``neg_delta`` (the simulator checks it against its own dctx and
+    ctx); NPM_ATTN_ROWDOT=0 is the pass over dctx and ctx inside npm_mha_core_bwd.  Same results either way."""
+    from oracle import np_oracle as O
+    D = npm.device
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal([2, 8, 256]).astype(np.float32)
+    dy = rng.standard_normal([2, 8, 256]).astype(np.float32)
+    outs = {}
+    for rowdot in (True, False):
+        monkeypatch.setattr(D, 'ATTN_ROWDOT', rowdot)
+        np.random.seed(0)
+        layer = npm.layers.MultiHeadAttention(num_heads=2)
+        layer(x)
+        for n in ('_wq', '_wk', '_wv', '_wo'):
+            getattr(layer, n).set(np.asarray(getattr(layer, n)) / np.float32(16.0))
+        out = layer(x)
+        assert layer._core and layer._key_dim == 128
+        import hostsim
+        sim = npm._C._LIB
+        seen = []
+        monkeypatch.setattr(sim, 'npm_mha_core_bwd',
+                            lambda cref, inner=type(sim).npm_mha_core_bwd.__get__(sim), seen=seen: (seen.append(bool(hostsim._deref(cref).neg_delta)), inner(cref))[1])
+        grads = [np.asarray(g) for g in layer(dy, backprop=True, learning_rate=0.01)]
+        assert seen == [rowdot]
+        outs[rowdot] = [np.asarray(out)] + grads + [np.asarray(getattr(layer, n)).copy() for n in ('_wq', '_wo', '_bq', '_bo')]
+    for a, b in zip(outs[True], outs[False]):
+        np.testing.assert_array_equal(a, b)          # (the simulator's backward does not depend on who computed the row terms)
