@@ -131,7 +131,7 @@ enum {
     NPM_TUNE_GEMM_BUF_EPILOGUE = 3,
     NPM_TUNE_CONV_DMA = 4,
     NPM_TUNE_GEMM_WIDE_TILE = 5,     /* 128 x 256 block tile (8 waves) where n % 256 == 0: 0 never (default), 1 always, 2 NN / NT, 3 NT only */
-    NPM_TUNE_LN_BWD_BLOCKS = 6,      /* LayerNorm backward grid: n > 0 blocks of 4 waves per CU (rounds 1-4: 4); n < 0 |n| blocks of 12 waves per CU where the row width allows (default -1: a quarter of the partial rows, one column-sum launch behind the kernel instead of two) */
+    NPM_TUNE_LN_BWD_BLOCKS = 6,      /* blocks per CU of the LayerNorm backward grid (default 4) */
     NPM_TUNE_EW_GRID_CAP = 7,        /* max blocks of the grid-stride elementwise kernels (default 2^20) */
     NPM_TUNE_CONV_WGRAD_BLOCKS = 8,  /* grad_w split-K blocks per CU: 0 (default) best of 3 and 4, 3 / 4 pinned, 6 / 9 / 12 several generations of shorter K ranges (measured at C3: 14.44 -> 14.6-15.0 ms), -1 unbalanced ceil(3 CUs / tiles) */
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */

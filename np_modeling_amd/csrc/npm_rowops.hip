@@ -11,7 +11,7 @@
 
 namespace {
 
-int g_ln_bwd_blocks_per_cu = -1;    // NPM_TUNE_LN_BWD_BLOCKS (see npm_layernorm_bwd)
+int g_ln_bwd_blocks_per_cu = 4;     // NPM_TUNE_LN_BWD_BLOCKS
 // NPM_TUNE_LN_NT_SPLIT = backward mode + 4 * forward mode; a mode: 0 nontemporal hint on loads and stores, 1 on the loads only, 2 on
 // the stores only (d in (512, 1024] -- the encoder's rows; other widths take mode 0).  Default 1 + 4 * 1: measured INSIDE the
 // encoder step (profiles/r05_ln_nt_split.log) the backward runs 0.377 -> 0.362 ms with its dx stored under the default policy
@@ -583,8 +583,8 @@ layernorm_fwd_generic(const float *__restrict__ x, const float *__restrict__ gam
 // Backward: each wave walks rows (grid-stride) and keeps its dgamma/dbeta partials for the
 // columns it owns in registers; every wave writes one partial row and a column sum over
 // the wave partials (fixed order, reproducible) finishes the job.
-template <int VPL, bool NT, bool NTS = NT, int WPB = ROWS_PER_BLOCK>
-__global__ void __launch_bounds__(64 * WPB)
+template <int VPL, bool NT, bool NTS = NT>
+__global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
                      const float *__restrict__ rstd, const float *__restrict__ gamma,
                      const float *__restrict__ residual, long rows, int d, float *__restrict__ dx,
@@ -603,7 +603,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
     // The residual row is requested together with dz and x, before anything waits (it used to be loaded after the
     // two reductions: 0.459 -> 0.429 ms at 131072 x 1024).  Prefetching the next row's dz / x under the reductions
     // doubled the registers and changed nothing (0.334 -> 0.330 ms): this kernel is not latency-bound.
-    for (long row = (long)blockIdx.x * WPB + wave; row < rows; row += (long)gridDim.x * WPB) {
+    for (long row = (long)blockIdx.x * ROWS_PER_BLOCK + wave; row < rows; row += (long)gridDim.x * ROWS_PER_BLOCK) {
         float4 g[VPL], yh[VPL], res[VPL];
         load_row<VPL, NT>(dz + row * d, nvec, lane, g, 0.f);
         load_row<VPL, NT>(x + row * d, nvec, lane, yh, 0.f);
@@ -637,7 +637,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
     }
     // One partial row per BLOCK, dgamma and dbeta side by side ([blocks][2 d]): the waves' partials meet in LDS and
     // wave 0 adds them in wave order (fixed: reproducible); one column sum over the block partials finishes both.
-    __shared__ float4 red[WPB - 1][VPL * WAVE];
+    __shared__ float4 red[3][VPL * WAVE];
     float4 *prow = reinterpret_cast<float4 *>(part + (long)blockIdx.x * 2 * d);
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
@@ -654,7 +654,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
                 const int c = lane + WAVE * j;
                 float4 t = mine[j];
 #pragma unroll
-                for (int w = 0; w < WPB - 1; ++w) {
+                for (int w = 0; w < 3; ++w) {
                     const float4 o = red[w][c];
                     t.x += o.x; t.y += o.y; t.z += o.z; t.w += o.w;
                 }
@@ -693,7 +693,7 @@ layernorm_bwd_dx_generic(const float *__restrict__ dz, const float *__restrict__
 }  // namespace
 
 namespace npm {
-void set_ln_bwd_blocks(int v) { g_ln_bwd_blocks_per_cu = v != 0 ? v : 4; }
+void set_ln_bwd_blocks(int v) { g_ln_bwd_blocks_per_cu = v > 0 ? v : 4; }
 void set_ln_nt_split(int v) { g_ln_nt_split = v; }
 void set_stream_nt(int v) { g_stream_nt = v != 0; }
 bool stream_nt_enabled(size_t bytes) { return stream_nt(bytes); }
@@ -868,22 +868,14 @@ int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const 
     const bool fast = d % 4 == 0 && d <= 4096 && aligned16(dz) && aligned16(x) && aligned16(dx) &&
                       aligned16(gamma) && (residual == nullptr || aligned16(residual));
     if (fast) {
-        // g_ln_bwd_blocks_per_cu > 0: blocks of 4 waves; < 0 (default -1): that many blocks of TWELVE waves per CU (the kernel holds
-        // 164 registers: three waves per SIMD, so twelve waves are what a CU runs either way) -- a quarter of the partial rows, and
-        // the column sum behind the kernel is one launch over 256 rows instead of two stages over 1 024
         const bool nt_rows = stream_nt(sizeof(float) * (size_t)rows * (size_t)d);
-        const bool wide = g_ln_bwd_blocks_per_cu < 0 && nt_rows && (g_ln_nt_split & 3) == 1 && d > 512 && d <= 1024;
-        const int wpb = wide ? 12 : ROWS_PER_BLOCK;
-        const long row_blocks = (rows + wpb - 1) / wpb;
-        const int per_cu = g_ln_bwd_blocks_per_cu < 0 ? (wide ? -g_ln_bwd_blocks_per_cu : 4) : g_ln_bwd_blocks_per_cu;
-        const int grid = (int)std::min<long>(row_blocks, (long)per_cu * npm::ctx().num_cus);
+        const long row_blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+        const int grid = (int)std::min<long>(row_blocks, (long)g_ln_bwd_blocks_per_cu * npm::ctx().num_cus);
         npm::Scratch part;
         int rc = part.alloc(sizeof(float) * 2 * (size_t)grid * d);
         if (rc) return rc;
         float *pp = (float *)part.ptr;                     // [grid][2 d]: dgamma partials | dbeta partials
-        if (wide)
-            hipLaunchKernelGGL((layernorm_bwd_kernel<4, true, false, 12>), dim3(grid), dim3(768), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
-        else if (nt_rows && (g_ln_nt_split & 3) == 1 && d > 512 && d <= 1024)
+        if (nt_rows && (g_ln_nt_split & 3) == 1 && d > 512 && d <= 1024)
             hipLaunchKernelGGL((layernorm_bwd_kernel<4, true, false>), dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);
         else if (stream_nt(sizeof(float) * (size_t)rows * (size_t)d) && (g_ln_nt_split & 3) == 2 && d > 512 && d <= 1024)
             hipLaunchKernelGGL((layernorm_bwd_kernel<4, false, true>), dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp);

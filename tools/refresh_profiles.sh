@@ -4,12 +4,16 @@
 # Round 3: the split-precision modes are measured by bench.py's own alt_math regions only (no microbenchmarks, no
 # per-mode sweeps: VERDICT round 2 item 9); new: the exchange path A/B on one GPU, the masked attention timings,
 # the decoder line, the HBM-side probe and the TCC request counters of the weight-gradient GEMM.
+# NPM_REFRESH_PART=1 | 2 runs one half (a gpurun call is limited to 20 minutes): 1 = PMC traffic, bench, clocks, configs, GEMM shapes,
+# row kernels, the round-5 logs; 2 = attention, parity, exchange path, kernel traces, counters, timelines.
 set -o pipefail
+PART=${NPM_REFRESH_PART:-all}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 R=${NPM_ROUND:-r05}
 OUT=$REPO/gpurun_out/profiles_new
 mkdir -p "$OUT"
 cd "$REPO"
+if [ "$PART" != 2 ]; then
 # FIRST the PMC traffic passes: the bench line below quotes their figure (roofline.traffic), so both come from THIS session and
 # THIS build (profiles/pmc_traffic.json carries the session name and the sources' id; bench.py refuses any other build's)
 echo "== PMC traffic (two passes)"
@@ -28,6 +32,15 @@ echo "== config bench (f32)"; { timeout -k 10 300 python tools/config_bench.py -
   echo "-- C3 with the K loop of forward / grad_x by taps (NPM_TUNE 16=0: round 3) and by 16-channel chunks (16=1: default), alternating"; for k in 0 1 0 1; do echo "NPM_TUNE=16=$k"; NPM_TUNE=16=$k timeout -k 10 200 python tools/config_bench.py --only C3 --kernels; done; } > "$OUT/${R}_config_bench.log" 2>&1
 echo "== gemm shapes (f32)"; timeout -k 10 200 python tools/gemm_bench.py --tune 10=0 > "$OUT/${R}_gemm_shapes.log" 2>&1
 echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/${R}_rowops.log" 2>&1
+echo "== round 5: exchange shadow (the 8-GPU step bounded on one GPU), LayerNorm hint placement, row terms from the dctx GEMM"
+timeout -k 10 500 python tools/exchange_shadow.py > "$OUT/${R}_exchange_shadow.log" 2>&1
+{ echo "# LayerNorm: where the nontemporal hint sits (NPM_TUNE_LN_NT_SPLIT = backward mode + 4 * forward mode; mode 0 loads and stores, 1 loads only, 2 stores only)";
+  echo "# tools/ln_nt_split.py: backward + residual alone, 131072 x 1024, cold caches / right behind the kernel that wrote dz"; timeout -k 10 120 python tools/ln_nt_split.py;
+  echo "# tools/ln_instep.sh: inside the encoder step (bench.py hbm_kernels: (ms per call incl. the column sum, fraction of 8 TB/s)); 5 = shipped, 0 = rounds 2-4, 1 = backward only, 9 = forward stores only"; timeout -k 10 600 bash tools/ln_instep.sh 19=5 19=0 19=1 19=9; } > "$OUT/${R}_ln_nt_split.log" 2>&1
+{ echo "# bench.py --steps 20 --warmup 5 (headline step only), alternating: row terms from the epilogue of the dctx GEMM (NPM_ATTN_ROWDOT=1, shipped) against the pass inside npm_mha_core_bwd (0, rounds 3-4)";
+  for i in 1 2 3; do for r in 1 0; do echo "NPM_ATTN_ROWDOT=$r: $(NPM_ATTN_ROWDOT=$r timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-alt-math --no-configs --no-cpu-baseline 2>/dev/null | python3 tools/bench_brief.py)"; done; done; } > "$OUT/${R}_attn_rowdot_ab.log" 2>&1
+fi   # part 1
+if [ "$PART" != 1 ]; then
 echo "== fused attention core"; { echo "-- saved scores (the default from head size 64 up), then recomputing; medians of 15 back-to-back launches after 30 untimed";
   timeout -k 10 100 python tools/attn_bench.py --save-scores --warm 30 --reps 15; timeout -k 10 100 python tools/attn_bench.py --warm 30 --reps 15;
   echo "-- the 4-wave 32 x 32 x 2 forward (NPM_TUNE 17=0: round 3's), saved scores then recomputing"; timeout -k 10 100 python tools/attn_bench.py --save-scores --warm 30 --reps 15 --tune 17=0; timeout -k 10 100 python tools/attn_bench.py --warm 30 --reps 15 --tune 17=0;
@@ -69,5 +82,6 @@ echo "== SQ / TCC counters of the kernels that are in the step and in the config
 { echo "### config_bench --only C3, K loop by 16-channel chunks (default)"; tools/pmc/groups.sh "$OUT/pmc_c2" 'conv_' tcc -- tools/config_bench.py --only C3 --min-seconds 0.05; echo "### ... by taps (NPM_TUNE=16=0, round 3)"; NPM_TUNE=16=0 tools/pmc/groups.sh "$OUT/pmc_c3" 'conv_fwd' "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_128B_sum;TCC_HIT_sum TCC_MISS_sum" -- tools/config_bench.py --only C3 --min-seconds 0.05; } > "$OUT/${R}_pmc_conv_tcc.log" 2>&1
 echo "== GEMM timeline"; { for a in "1024" "4096" "131072 4096 1024" "131072 128 576" "c2" "qk"; do echo "### gemm_trace.py $a"; timeout -k 10 120 python tools/gemm_trace.py $a; done; } > "$OUT/${R}_gemm_timeline.log" 2>&1
 echo "== the reference's own assertion form"; timeout -k 10 300 python tools/reference_form_report.py > "$OUT/${R}_reference_form.md" 2> "$OUT/refform.err"
+fi   # part 2
 rm -rf "$OUT"/prof "$OUT"/prof_cfg "$OUT"/prof_dec "$OUT"/pmc_FETCH_SIZE "$OUT"/pmc_WRITE_SIZE "$OUT"/pmc_tn "$OUT"/pmc_attn "$OUT"/pmc_a1 "$OUT"/pmc_a2 "$OUT"/pmc_a3 "$OUT"/pmc_g "$OUT"/pmc_c1 "$OUT"/pmc_c2 "$OUT"/pmc_c3
 echo "== done"; ls "$OUT"
