@@ -1487,7 +1487,7 @@ mha_bwd16_kernel(const MhaArgs p) {
 // issued in the dV product, BEHIND every compiler-visible load of the tile (row terms, scores, mask bytes, old dQ).
 // ---------------------------------------------------------------------------------------------------------------
 template <int D, bool MASK, bool SAVED>
-__global__ void __launch_bounds__(512, D == 16 ? 4 : 2)      // (waves per SIMD) D = 16: 48 KB of LDS, two blocks per CU: 128 registers per wave
+__global__ void __launch_bounds__(512, D <= 32 ? 4 : 2)      // (waves per SIMD) D <= 32: 64 KB of LDS, two blocks per CU: 128 registers per wave
 mha_bwd8_kernel(const MhaArgs p) {
     using T = Tile<D>;
     using TS = Tile<128>;
@@ -1498,9 +1498,18 @@ mha_bwd8_kernel(const MhaArgs p) {
     constexpr int DQT = NC == 8 ? 2 : 1;                                         // query halves a wave's dQ slice covers
     constexpr int NB = NC < 4 ? NC : 4;
     constexpr bool CTP = D < 128;                                                // compile-time stage / buffer parity (see `visit`)
+    // Head size 16: the dQ product has only two 16 x 16 output tiles -- two of the eight waves carried it (32 MFMAs beside the 32
+    // of their other four products; their SIMDs were the kernel's critical path).  SPREAD: every wave multiplies its OWN 16 keys'
+    // dS (its own columns of the dS tile: no other wave reads them) into a partial dQ^T tile, 8 MFMAs, writes it to LDS, and
+    // behind the next barrier all 512 threads add the eight partials of one (query, d) element each, in wave order.
+    // (Head size 32 the same way: 6.6 -> 8.5 ms -- its four dQ waves sit on four different SIMDs already, and the partial tiles are
+    // twice as large: 16 reads per thread behind the barrier.)
+    constexpr bool SPREAD = NC == 1;
+    constexpr int PQBUF = 8 * 32 * D;                                            // SPREAD: eight partial [32 q][D] tiles (floats)
     static_assert(!(MASK && SAVED), "saved scores carry the mask");
-    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + 2 * DSBUF];
+    __shared__ __attribute__((aligned(16))) float smem[KBLK + 4 * QTILE + (SPREAD ? DSBUF + 2 * PQBUF : 2 * DSBUF)];
     float *const sKB = smem, *const sQ = sKB + KBLK, *const sDO = sQ + 2 * QTILE, *const sDS = sDO + 2 * QTILE;
+    float *const sPQ = sDS + DSBUF;                                              // SPREAD: [2][8][32][D]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // 0 .. 7
@@ -1557,15 +1566,25 @@ mha_bwd8_kernel(const MhaArgs p) {
     const float c = p.scale * LOG2E;
     const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
     const int kvl = 16 * wave + l16;
-    const int dq_voff = (int)((l16 * p.dq_pitch + 16 * dqs + 4 * kk) * 4);
+    const int dq_voff = SPREAD ? (int)(((tid / D) * p.dq_pitch + (tid % D)) * 4)            // SPREAD: thread = (query tid / D (+ 512 / D ..), d tid % D)
+                               : (int)((l16 * p.dq_pitch + 16 * dqs + 4 * kk) * 4);
+    const int dq_pass = (512 / D) * (int)p.dq_pitch * 4;                                    // SPREAD: bytes between a thread's NC elements
     const int dq_sub = 16 * (int)p.dq_pitch * 4;
+    // SPREAD: this wave's own keys -- dS rows l16 (+ 16 t) at the chunk of keys 16 wave + 4 kk, K rows 16 wave + 4 kk + s at column l16
+    // (+ 16 x), the lane's slot of the wave's partial tile
+    const int own_ds = TS::chunk(l16, 4 * wave + kk), own_pq = wave * 32 * D + l16 * D + 4 * kk;
+    int own_k[4];
+#pragma unroll
+    for (int s = 0; s < 4; ++s) own_k[s] = T::elem(4 * kk + s, l16) + 16 * wave * D;
 
     // ---- which tiles exist
     const unsigned char *const sk = p.skip ? p.skip + b * p.skip_sb + h * p.skip_sh : nullptr;
     auto load_tiles = [&](int kb, int &bytes) -> unsigned long {                // bit qt: tile (qt, kb) is visited
         if (!sk) return ~0ul;
-        bytes = lane < nqt ? (int)sk[(long)lane * p.skip_nkb + kb] : 0;
-        if (MASK && p.skip_all && lane < nqt) bytes |= (int)sk[p.skip_all + (long)lane * p.skip_nkb + kb] << 8;   // bits 8..15: "all"
+        int ln = lane;
+        asm volatile("" : "+v"(ln));                                            // (once per key block: not worth a register pair held, or spilled, across the tile loop)
+        bytes = ln < nqt ? (int)sk[(long)ln * p.skip_nkb + kb] : 0;
+        if (MASK && p.skip_all && ln < nqt) bytes |= (int)sk[p.skip_all + (long)ln * p.skip_nkb + kb] << 8;   // bits 8..15: "all"
         const unsigned long any = __builtin_amdgcn_ballot_w64((bytes & 0xff) != 0);
         return any ? any : 1ul;                                                 // an empty key block still visits tile 0 (all waves idle in it)
     };
@@ -1604,7 +1623,19 @@ mha_bwd8_kernel(const MhaArgs p) {
     // ---- dQ^T[d, q] (+)= K^T[d, kv] dS^T[kv, q] of tile `tile` over the 128 keys of the block, from dS buffer `buf`;
     //      `oldq` = what earlier key blocks left there; the DMA pieces of tile `nq` (stage `nstage`) go out inside
     auto dq_phase = [&](int tile, int buf, const f32x4 (&oldq)[DQT]) __attribute__((always_inline)) {
-        if (dq_wave) {
+        if constexpr (SPREAD) {
+            const float *pp = sPQ + buf * PQBUF + tid;
+#pragma unroll
+            for (int x = 0; x < NC; ++x) {
+                float part[8];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) part[w] = pp[w * 32 * D + 512 * x];
+                float sum = oldq[0][x];
+#pragma unroll
+                for (int w = 0; w < 8; ++w) sum += part[w];
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), rsrcDQ, dq_voff, tile * 32 * (int)p.dq_pitch * 4 + x * dq_pass, 0);
+            }
+        } else if (dq_wave) {
             const float *tS = sDS + buf * DSBUF + (NC == 8 ? 0 : dqh * SROWS16);
             f32x4 acc[DQT];
 #pragma unroll
@@ -1650,7 +1681,9 @@ mha_bwd8_kernel(const MhaArgs p) {
 #pragma unroll
         for (int t = 0; t < NC; ++t) { dK[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         const int svoff = kvok ? (kvrow + 4 * kk * p.seq_kv) * 4 : OOB;          // saved scores: this lane's key, its rows 4 kk ..
-        const int mvoff = kvok ? kvrow + 4 * kk * (int)p.mask_sq : OOB;          // mask bytes, the same way
+        int kkm = kk;
+        if (MASK) asm volatile("" : "+v"(kkm));                                  // (the product below once per key block, not a register held across the tile loop)
+        const int mvoff = kvok ? kvrow + 4 * kkm * (int)p.mask_sq : OOB;         // mask bytes, the same way
 
         int pend = -1;                                                           // tile whose dQ product is still to come
         f32x4 pend_old[DQT];
@@ -1675,7 +1708,7 @@ mha_bwd8_kernel(const MhaArgs p) {
             asm volatile("" ::: "memory");
             n_inflight = 0;
             const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
-            float *const tDS = sDS + cur * DSBUF;
+            float *const tDS = sDS + (SPREAD ? 0 : cur * DSBUF);
             const int q0 = 32 * qt;
             const int tile_bits = sk ? __builtin_amdgcn_readlane(cur_bytes, qt & 63) : 0xff;
             const bool on = !sk || ((tile_bits >> wave) & 1);                        // this wave's 32 x 16 sub-tile has work
@@ -1717,7 +1750,12 @@ mha_bwd8_kernel(const MhaArgs p) {
             f32x4 own_old[DQT];
 #pragma unroll
             for (int t = 0; t < DQT; ++t) own_old[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (dq_wave) {
+            if constexpr (SPREAD) {
+                const auto rsrcOld = ((written >> (qt & 63)) & 1) || (!sk && kb > 0) ? rsrcDQ : rsrcNone;
+#pragma unroll
+                for (int x = 0; x < NC; ++x)
+                    own_old[0][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcOld, dq_voff, q0 * (int)p.dq_pitch * 4 + x * dq_pass, 0));
+            } else if (dq_wave) {
                 const auto rsrcOld = ((written >> (qt & 63)) & 1) || (!sk && kb > 0) ? rsrcDQ : rsrcNone;     // nothing stored yet: reads 0
                 const int dq_tile = q0 * (int)p.dq_pitch * 4 + (NC == 8 ? 0 : dqh * dq_sub);
 #pragma unroll
@@ -1790,6 +1828,16 @@ mha_bwd8_kernel(const MhaArgs p) {
                     }
                 // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (NV vector reads, NC MFMAs)
                 float ea[2][NV][4];
+                float akq[NC][4];
+                float4 daq[2];
+                if constexpr (SPREAD) {                                          // own dS rows back (transposed), own K rows: used behind dV
+#pragma unroll
+                    for (int x = 0; x < NC; ++x)
+#pragma unroll
+                        for (int s = 0; s < 4; ++s) akq[x][s] = sKB[own_k[s] ^ (x << 4)];    // column + 16: chunk position bit 2 flips
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) daq[t] = ld4(tDS + own_ds + t * SROWS16);
+                }
 #pragma unroll
                 for (int v = 0; v < NV; ++v) ldv<VW>(tDO + vb[0] + 64 * v, ea[0][v]);
 #pragma unroll
@@ -1809,11 +1857,38 @@ mha_bwd8_kernel(const MhaArgs p) {
                     for (int x = 0; x < NC; ++x) dV[x] = MFMA16(ea[st & 1][x / VW][x % VW], P[t][r], dV[x]);
                     FENCE();
                 }
+                if constexpr (SPREAD) {
+                    // ---- partial dQ^T[d, q] = K^T[d, own keys] dS^T[own keys, q]: rows d = 4 kk + r, column q = 16 t + l16
+                    f32x4 pq[NC][2];
+#pragma unroll
+                    for (int x = 0; x < NC; ++x)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t) {
+                            pq[x][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                            pq[x][t] = MFMA16(akq[x][0], daq[t].x, pq[x][t]);
+                            pq[x][t] = MFMA16(akq[x][1], daq[t].y, pq[x][t]);
+                            pq[x][t] = MFMA16(akq[x][2], daq[t].z, pq[x][t]);
+                            pq[x][t] = MFMA16(akq[x][3], daq[t].w, pq[x][t]);
+                        }
+                    FENCE();
+#pragma unroll
+                    for (int x = 0; x < NC; ++x)
+#pragma unroll
+                        for (int t = 0; t < 2; ++t)
+                            *reinterpret_cast<float4 *>(sPQ + cur * PQBUF + own_pq + t * ROWS16 + 16 * x) =
+                                make_float4(pq[x][t][0], pq[x][t][1], pq[x][t][2], pq[x][t][3]);
+                }
             } else {
+                if constexpr (SPREAD) {
+#pragma unroll
+                    for (int x = 0; x < 2 * NC; ++x)
+                        *reinterpret_cast<float4 *>(sPQ + cur * PQBUF + own_pq + (x >> 1) * 16 + (x & 1) * ROWS16) = make_float4(0.f, 0.f, 0.f, 0.f);
+                } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 4; ++r) tDS[wsS[r] + t * SROWS16] = 0.f;
+                }
                 if (nq >= 0) {
                     issue_q(nq, cur ^ 1);
                     issue_do(nq, cur ^ 1);
@@ -1889,7 +1964,13 @@ mha_bwd8_kernel(const MhaArgs p) {
         cur_bytes = nxt_bytes;
     }
     // ---- query tiles no key block visited (every position masked): their dQ rows are zero
-    if (sk && dq_wave) {
+    if (SPREAD && sk) {
+        for (int qt = 0; qt < nqt; ++qt)
+            if (!((written >> (qt & 63)) & 1)) {
+#pragma unroll
+                for (int x = 0; x < NC; ++x) __builtin_amdgcn_raw_buffer_store_b32(0u, rsrcDQ, dq_voff, qt * 32 * (int)p.dq_pitch * 4 + x * dq_pass, 0);
+            }
+    } else if (sk && dq_wave) {
         for (int qt = 0; qt < nqt; ++qt) {
             if ((written >> (qt & 63)) & 1) continue;
             const int dq_tile = qt * 32 * (int)p.dq_pitch * 4 + (NC == 8 ? 0 : dqh * dq_sub);
