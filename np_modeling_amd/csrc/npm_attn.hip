@@ -72,25 +72,30 @@ struct MhaArgs {
 //     such read was a 2-way conflict, 27.6 % of the LDS cycles of mha_bwd16_kernel and 33 % of mha_fwd8_kernel's
 //     (profiles/r04_pmc_attn_sq.log; the model reproduces both figures).  Position bit 3 = row bit 3 XOR row bit 2 separates them;
 //   * ds_read_b32 / ds_write_b32 along a row.
-// Rows shorter than a 256-byte bank line (D = 32, 16) put 2 / 4 rows on one line, so their positions come from row bits 1.. / 2..
+// Rows shorter than a 256-byte bank line (D = 32, 16) put 2 / 4 rows on one line: there the rows 4 kk + j of a column read (kk =
+// 0, 1 in one ds_read_b32 / b64 lane group) start on the same banks whatever the chunk swizzle does inside a row, so the ROW itself
+// moves too -- row r sits at row position r ^ (bit 2 of r) (neighbours swap places in every second group of four), and the chunk
+// position comes from row bits 1 .. 3 (D = 32) / bit 3 (D = 16): every pattern conflict-free in the model; measured before (round 5
+// counters, backward): 19 % (D = 32) and 34 % (D = 16) of the LDS cycles were conflicts.
 template <int D>
 struct Tile {
     static constexpr int CPR = D / 4;                           // chunks per row
     static constexpr int SWZ = (CPR < 16 ? CPR : 16) - 1;
     __host__ __device__ static constexpr int sw(int row) {
         return D >= 64 ? ((row & 15) ^ ((row & 4) << 1))
-             : D == 32 ? (((row >> 1) & 3) | ((((row >> 2) ^ (row >> 3)) & 1) << 2))
-                       : (((row >> 2) & 1) | ((((row >> 2) ^ (row >> 3)) & 1) << 1));
+             : D == 32 ? (((row >> 1) & 1) | (((row >> 3) & 1) << 1) | (((row >> 2) & 1) << 2))
+                       : (((row >> 3) & 1) << 1);
     }
+    __host__ __device__ static constexpr int prow(int row) { return D <= 32 ? row ^ ((row >> 2) & 1) : row; }   // row position (an involution)
     static constexpr int PIECE_ROWS = 256 / D;                  // rows per 1 KiB DMA piece
     static constexpr int NG = D / 8;                            // k groups of 8 along a row
     static constexpr int NB = NG < 8 ? NG : 8;                  // lane-dependent bases of the row reads
     static_assert(D == 16 || D == 32 || D == 64 || D == 128, "head dim");
-    __device__ static __forceinline__ int chunk(int row, int c) { return row * D + ((c ^ sw(row)) << 2); }
-    __device__ static __forceinline__ int elem(int row, int col) { return row * D + ((((col >> 2) ^ sw(row)) << 2) | (col & 3)); }
+    __device__ static __forceinline__ int chunk(int row, int c) { return prow(row) * D + ((c ^ sw(row)) << 2); }
+    __device__ static __forceinline__ int elem(int row, int col) { return prow(row) * D + ((((col >> 2) ^ sw(row)) << 2) | (col & 3)); }
     // byte offset (inside a [rows][pitch] global matrix) that lane `lane` of DMA piece `piece` copies from
     __device__ static __forceinline__ unsigned src(int lane, int piece, long pitch) {
-        const int row = piece * PIECE_ROWS + lane / CPR;
+        const int row = prow(piece * PIECE_ROWS + lane / CPR);                 // the row whose position this lane's 16 bytes are
         const int c = (lane % CPR) ^ sw(row);
         return (unsigned)((row * pitch + c * 4) * 4);
     }
@@ -1572,7 +1577,11 @@ mha_bwd8_kernel(const MhaArgs p) {
     const int dq_sub = 16 * (int)p.dq_pitch * 4;
     // SPREAD: this wave's own keys -- dS rows l16 (+ 16 t) at the chunk of keys 16 wave + 4 kk, K rows 16 wave + 4 kk + s at column l16
     // (+ 16 x), the lane's slot of the wave's partial tile
-    const int own_ds = TS::chunk(l16, 4 * wave + kk), own_pq = wave * 32 * D + l16 * D + 4 * kk;
+    // (the partial tile's 16-byte chunks are swizzled by the query, chunk position c ^ ((q >> 1) & 3): ds_write_b128 is served in groups
+    // of eight neighbouring lanes over 32 banks, and eight queries' chunk c straight would be a 4-way conflict -- 48 extra LDS cycles
+    // per wave and tile, measured)
+    static_assert(!SPREAD || D == 16, "the partial tile's swizzle is written for 16-float rows");
+    const int own_ds = TS::chunk(l16, 4 * wave + kk), own_pq = wave * 32 * D + l16 * D + ((kk ^ ((l16 >> 1) & 3)) << 2);
     int own_k[4];
 #pragma unroll
     for (int s = 0; s < 4; ++s) own_k[s] = T::elem(4 * kk + s, l16) + 16 * wave * D;
@@ -1624,7 +1633,7 @@ mha_bwd8_kernel(const MhaArgs p) {
     //      `oldq` = what earlier key blocks left there; the DMA pieces of tile `nq` (stage `nstage`) go out inside
     auto dq_phase = [&](int tile, int buf, const f32x4 (&oldq)[DQT]) __attribute__((always_inline)) {
         if constexpr (SPREAD) {
-            const float *pp = sPQ + buf * PQBUF + tid;
+            const float *pp = sPQ + buf * PQBUF + ((tid & ~15) | ((((tid >> 2) ^ (tid >> 5)) & 3) << 2) | (tid & 3));
 #pragma unroll
             for (int x = 0; x < NC; ++x) {
                 float part[8];
