@@ -1571,12 +1571,11 @@ mha_bwd8_kernel(const MhaArgs p) {
     const float c = p.scale * LOG2E;
     const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
     const int kvl = 16 * wave + l16;
-    const int dq_voff = SPREAD ? (int)(((tid / D) * p.dq_pitch + (tid % D)) * 4)            // SPREAD: thread = (query tid / D (+ 512 / D ..), d tid % D)
+    const int dq_voff = SPREAD ? (int)(((tid >> 4) * p.dq_pitch + (tid & 15)) * 4)          // SPREAD: thread = (query tid / 16, d tid % 16)
                                : (int)((l16 * p.dq_pitch + 16 * dqs + 4 * kk) * 4);
-    const int dq_pass = (512 / D) * (int)p.dq_pitch * 4;                                    // SPREAD: bytes between a thread's NC elements
     const int dq_sub = 16 * (int)p.dq_pitch * 4;
-    // SPREAD: this wave's own keys -- dS rows l16 (+ 16 t) at the chunk of keys 16 wave + 4 kk, K rows 16 wave + 4 kk + s at column l16
-    // (+ 16 x), the lane's slot of the wave's partial tile
+    // SPREAD: this wave's own keys -- dS rows l16 (+ 16 t) at the chunk of keys 16 wave + 4 kk, K rows 16 wave + 4 kk + s at column l16,
+    // the lane's slot of the wave's partial tile
     // (the partial tile's 16-byte chunks are swizzled by the query, chunk position c ^ ((q >> 1) & 3): ds_write_b128 is served in groups
     // of eight neighbouring lanes over 32 banks, and eight queries' chunk c straight would be a 4-way conflict -- 48 extra LDS cycles
     // per wave and tile, measured)
@@ -1634,16 +1633,13 @@ mha_bwd8_kernel(const MhaArgs p) {
     auto dq_phase = [&](int tile, int buf, const f32x4 (&oldq)[DQT]) __attribute__((always_inline)) {
         if constexpr (SPREAD) {
             const float *pp = sPQ + buf * PQBUF + ((tid & ~15) | ((((tid >> 2) ^ (tid >> 5)) & 3) << 2) | (tid & 3));
+            float part[8];
 #pragma unroll
-            for (int x = 0; x < NC; ++x) {
-                float part[8];
+            for (int w = 0; w < 8; ++w) part[w] = pp[w * 32 * D];
+            float sum = oldq[0][0];
 #pragma unroll
-                for (int w = 0; w < 8; ++w) part[w] = pp[w * 32 * D + 512 * x];
-                float sum = oldq[0][x];
-#pragma unroll
-                for (int w = 0; w < 8; ++w) sum += part[w];
-                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), rsrcDQ, dq_voff, tile * 32 * (int)p.dq_pitch * 4 + x * dq_pass, 0);
-            }
+            for (int w = 0; w < 8; ++w) sum += part[w];
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(sum), rsrcDQ, dq_voff, tile * 32 * (int)p.dq_pitch * 4, 0);
         } else if (dq_wave) {
             const float *tS = sDS + buf * DSBUF + (NC == 8 ? 0 : dqh * SROWS16);
             f32x4 acc[DQT];
@@ -1761,9 +1757,7 @@ mha_bwd8_kernel(const MhaArgs p) {
             for (int t = 0; t < DQT; ++t) own_old[t] = f32x4{0.f, 0.f, 0.f, 0.f};
             if constexpr (SPREAD) {
                 const auto rsrcOld = ((written >> (qt & 63)) & 1) || (!sk && kb > 0) ? rsrcDQ : rsrcNone;
-#pragma unroll
-                for (int x = 0; x < NC; ++x)
-                    own_old[0][x] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcOld, dq_voff, q0 * (int)p.dq_pitch * 4 + x * dq_pass, 0));
+                own_old[0][0] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcOld, dq_voff, q0 * (int)p.dq_pitch * 4, 0));
             } else if (dq_wave) {
                 const auto rsrcOld = ((written >> (qt & 63)) & 1) || (!sk && kb > 0) ? rsrcDQ : rsrcNone;     // nothing stored yet: reads 0
                 const int dq_tile = q0 * (int)p.dq_pitch * 4 + (NC == 8 ? 0 : dqh * dq_sub);
@@ -1837,13 +1831,11 @@ mha_bwd8_kernel(const MhaArgs p) {
                     }
                 // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (NV vector reads, NC MFMAs)
                 float ea[2][NV][4];
-                float akq[NC][4];
+                float akq[4];
                 float4 daq[2];
                 if constexpr (SPREAD) {                                          // own dS rows back (transposed), own K rows: used behind dV
 #pragma unroll
-                    for (int x = 0; x < NC; ++x)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) akq[x][s] = sKB[own_k[s] ^ (x << 4)];    // column + 16: chunk position bit 2 flips
+                    for (int s = 0; s < 4; ++s) akq[s] = sKB[own_k[s]];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) daq[t] = ld4(tDS + own_ds + t * SROWS16);
                 }
@@ -1868,30 +1860,25 @@ mha_bwd8_kernel(const MhaArgs p) {
                 }
                 if constexpr (SPREAD) {
                     // ---- partial dQ^T[d, q] = K^T[d, own keys] dS^T[own keys, q]: rows d = 4 kk + r, column q = 16 t + l16
-                    f32x4 pq[NC][2];
+                    f32x4 pq[2];
 #pragma unroll
-                    for (int x = 0; x < NC; ++x)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t) {
-                            pq[x][t] = f32x4{0.f, 0.f, 0.f, 0.f};
-                            pq[x][t] = MFMA16(akq[x][0], daq[t].x, pq[x][t]);
-                            pq[x][t] = MFMA16(akq[x][1], daq[t].y, pq[x][t]);
-                            pq[x][t] = MFMA16(akq[x][2], daq[t].z, pq[x][t]);
-                            pq[x][t] = MFMA16(akq[x][3], daq[t].w, pq[x][t]);
-                        }
+                    for (int t = 0; t < 2; ++t) {
+                        pq[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+                        pq[t] = MFMA16(akq[0], daq[t].x, pq[t]);
+                        pq[t] = MFMA16(akq[1], daq[t].y, pq[t]);
+                        pq[t] = MFMA16(akq[2], daq[t].z, pq[t]);
+                        pq[t] = MFMA16(akq[3], daq[t].w, pq[t]);
+                    }
                     FENCE();
 #pragma unroll
-                    for (int x = 0; x < NC; ++x)
-#pragma unroll
-                        for (int t = 0; t < 2; ++t)
-                            *reinterpret_cast<float4 *>(sPQ + cur * PQBUF + own_pq + t * ROWS16 + 16 * x) =
-                                make_float4(pq[x][t][0], pq[x][t][1], pq[x][t][2], pq[x][t][3]);
+                    for (int t = 0; t < 2; ++t)
+                        *reinterpret_cast<float4 *>(sPQ + cur * PQBUF + own_pq + t * ROWS16) = make_float4(pq[t][0], pq[t][1], pq[t][2], pq[t][3]);
                 }
             } else {
                 if constexpr (SPREAD) {
 #pragma unroll
-                    for (int x = 0; x < 2 * NC; ++x)
-                        *reinterpret_cast<float4 *>(sPQ + cur * PQBUF + own_pq + (x >> 1) * 16 + (x & 1) * ROWS16) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int t = 0; t < 2; ++t)
+                        *reinterpret_cast<float4 *>(sPQ + cur * PQBUF + own_pq + t * ROWS16) = make_float4(0.f, 0.f, 0.f, 0.f);
                 } else {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
@@ -1975,10 +1962,7 @@ mha_bwd8_kernel(const MhaArgs p) {
     // ---- query tiles no key block visited (every position masked): their dQ rows are zero
     if (SPREAD && sk) {
         for (int qt = 0; qt < nqt; ++qt)
-            if (!((written >> (qt & 63)) & 1)) {
-#pragma unroll
-                for (int x = 0; x < NC; ++x) __builtin_amdgcn_raw_buffer_store_b32(0u, rsrcDQ, dq_voff, qt * 32 * (int)p.dq_pitch * 4 + x * dq_pass, 0);
-            }
+            if (!((written >> (qt & 63)) & 1)) __builtin_amdgcn_raw_buffer_store_b32(0u, rsrcDQ, dq_voff, qt * 32 * (int)p.dq_pitch * 4, 0);
     } else if (sk && dq_wave) {
         for (int qt = 0; qt < nqt; ++qt) {
             if ((written >> (qt & 63)) & 1) continue;

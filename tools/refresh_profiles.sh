@@ -4,6 +4,8 @@
 # Round 3: the split-precision modes are measured by bench.py's own alt_math regions only (no microbenchmarks, no
 # per-mode sweeps: VERDICT round 2 item 9); new: the exchange path A/B on one GPU, the masked attention timings,
 # the decoder line, the HBM-side probe and the TCC request counters of the weight-gradient GEMM.
+# NPM_REFRESH_PART=pmc runs only the PMC traffic passes and the default bench line (after a change of the sources that does not
+# move any timing: profiles/pmc_traffic.json and the bench line name the build they were taken on).
 # NPM_REFRESH_PART=1 | 2 runs one half (a gpurun call is limited to 20 minutes): 1 = PMC traffic, bench, clocks, configs, GEMM shapes,
 # row kernels, the round-5 logs; 2 = attention, parity, exchange path, kernel traces, counters, timelines.
 set -o pipefail
@@ -25,6 +27,7 @@ python3 profiles/summarize_pmc.py "$OUT"/pmc_FETCH_SIZE/*/*_counter_collection.c
 cp "$OUT/pmc_traffic.json" profiles/pmc_traffic.json
 echo "== bench (default command)"; timeout -k 10 500 python bench.py > "$OUT/${R}_bench.json" 2> "$OUT/bench.err" || exit 1
 python3 -c "import json; d=json.load(open('$OUT/${R}_bench.json')); t=json.load(open('$OUT/pmc_traffic.json')); assert d['roofline']['traffic'] == t['gemm_family_bytes_per_launch'], (d['roofline']['traffic'], d['roofline'].get('traffic_source')); print('roofline.traffic =', d['roofline']['traffic'], 'from', t['session'])" || exit 1
+[ "$PART" == pmc ] && { echo "== done (PMC traffic and the bench line only)"; exit 0; }
 echo "== clock / power during 60 steps"; tools/clock_sampler.sh "$OUT/clocks_f32.log" -- timeout -k 10 200 python bench.py --steps 60 --warmup 3 --no-cpu-baseline --no-alt-math --no-configs > "$OUT/bench_60.json" 2>/dev/null
 { echo "bench.py --steps 60 --warmup 3, sysfs freq1_input / power1_input of the loaded card (tools/clock_sampler.sh)";
   echo "math f32: $(python3 -c "import json;d=json.load(open('$OUT/bench_60.json'));print(round(d['value'],1),'samples/s',round(d['ms_per_step'],2),'ms/step')")  $(python3 tools/clock_summary.py $OUT/clocks_f32.log)"; } > "$OUT/${R}_clock_power.log"
