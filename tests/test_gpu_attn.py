@@ -134,6 +134,7 @@ def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=Fals
 SHAPES = [  # b, h, sq, skv, d
     (1, 1, 1, 1, 16), (2, 3, 32, 32, 16), (2, 2, 33, 47, 32), (1, 2, 100, 257, 64), (2, 2, 128, 128, 128),
     (1, 3, 200, 130, 128), (3, 1, 31, 300, 16), (1, 1, 130, 5, 64), (1, 2, 512, 512, 128), (2, 8, 32, 128, 16),
+    (2, 2, 100, 300, 16), (1, 3, 70, 260, 32), (1, 2, 257, 129, 16),      # several query tiles x several key blocks, ragged: the spread dQ sum (16), two blocks per CU (32)
 ]
 
 
