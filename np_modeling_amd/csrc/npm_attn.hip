@@ -90,7 +90,7 @@ struct Tile {
     static constexpr int PIECE_ROWS = 256 / D;                  // rows per 1 KiB DMA piece
     static constexpr int NG = D / 8;                            // k groups of 8 along a row
     static constexpr int NB = NG < 8 ? NG : 8;                  // lane-dependent bases of the row reads
-    static_assert(D == 16 || D == 32 || D == 64 || D == 128, "head dim");
+    static_assert(D == 16 || D == 32 || D == 64 || D == 128 || D == 256, "head dim (256: the dS tile of a 256-key block)");
     __device__ static __forceinline__ int chunk(int row, int c) { return prow(row) * D + ((c ^ sw(row)) << 2); }
     __device__ static __forceinline__ int elem(int row, int col) { return prow(row) * D + ((((col >> 2) ^ sw(row)) << 2) | (col & 3)); }
     // byte offset (inside a [rows][pitch] global matrix) that lane `lane` of DMA piece `piece` copies from
@@ -1495,14 +1495,20 @@ template <int D, bool MASK, bool SAVED>
 __global__ void __launch_bounds__(512, D <= 32 ? 4 : 2)      // (waves per SIMD) D <= 32: 64 KB of LDS, two blocks per CU: 128 registers per wave
 mha_bwd8_kernel(const MhaArgs p) {
     using T = Tile<D>;
-    using TS = Tile<128>;
+    // Head size 64: a key block is TWO groups of 128 keys (KG = 2) -- wave w owns keys 16 w .. of each group.  With one group a tile
+    // of this head size is 128 MFMAs per wave under the same barrier, waits, row-term loads and dQ read-modify-write as the 256 of head
+    // size 128 (0.67 against 0.78 of the peak); with two the block has exactly the footprint of head size 128 (64 KB of K, 96
+    // accumulator / V-fragment registers, 160 KB of LDS), 256 MFMAs per tile, and half the key-block passes over Q, dO and dQ.
+    constexpr int KG = D == 64 ? 2 : 1;
+    constexpr int SP = 128 * KG;                                                 // keys of a block = floats of a dS tile row
+    using TS = Tile<SP>;
     constexpr int NC = D / 16;
-    constexpr int QTILE = 32 * D, KBLK = 128 * D, ROWS16 = 16 * D, SROWS16 = 16 * 128, DSBUF = 32 * 128;   // floats
-    constexpr int QP = D / 8, QPPW = QP >= 8 ? QP / 8 : 1, KPPW = D / 16;        // 1 KiB DMA pieces: Q / dO tile, per wave; K block per wave
+    constexpr int QTILE = 32 * D, KBLK = SP * D, ROWS16 = 16 * D, SROWS16 = 16 * SP, DSBUF = 32 * SP;       // floats
+    constexpr int QP = D / 8, QPPW = QP >= 8 ? QP / 8 : 1, KPPW = D / 16 * KG;   // 1 KiB DMA pieces: Q / dO tile, per wave; K block per wave
     constexpr int VW = D >= 64 ? 4 : D / 16, NV = NC / VW;                       // column-vector reads: width, reads per step
     constexpr int DQT = NC == 8 ? 2 : 1;                                         // query halves a wave's dQ slice covers
     constexpr int NB = NC < 4 ? NC : 4;
-    constexpr bool CTP = D < 128;                                                // compile-time stage / buffer parity (see `visit`)
+    constexpr bool CTP = D < 64;                                                 // compile-time stage / buffer parity (see `visit`)
     // Head size 16: the dQ product has only two 16 x 16 output tiles -- two of the eight waves carried it (32 MFMAs beside the 32
     // of their other four products; their SIMDs were the kernel's critical path).  SPREAD: every wave multiplies its OWN 16 keys'
     // dS (its own columns of the dS tile: no other wave reads them) into a partial dQ^T tile, 8 MFMAs, writes it to LDS, and
@@ -1563,13 +1569,13 @@ mha_bwd8_kernel(const MhaArgs p) {
     for (int j = 0; j < 4; ++j) {
         vb[j] = T::elem(4 * kk + j, VW * l16);                                  // column vectors: row 16 t + 4 kk + r; + t ROWS16 (+ 64)
         rbS[j] = TS::chunk(l16, 4 * j + kk);                                    // dS tile rows 16 t + l16; + t SROWS16 + (c >> 2) 64
-        wsS[j] = TS::elem(4 * kk + j, 16 * wave + l16);                         // dS elements: row 16 t + 4 kk + r, this lane's key
+        wsS[j] = TS::elem(4 * kk + j, 16 * wave + l16);                         // dS elements: row 16 t + 4 kk + r, this lane's key (+ 128 kg)
         wsK[j] = T::elem(4 * kk + j, 16 * dqs + l16);                           // K block: row 16 c + 4 kk + s, column of the dQ slice
     }
-    const float *const sKW = sKB + 16 * wave * D;                               // this wave's 16 key rows
+    const float *const sKW = sKB + 16 * wave * D;                               // this wave's 16 key rows (of group kg: + 128 kg D)
 
     const float c = p.scale * LOG2E;
-    const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + 127) / 128;
+    const int nqt = (p.seq_q + 31) / 32, nkb = (p.seq_kv + SP - 1) / SP;
     const int kvl = 16 * wave + l16;
     const int dq_voff = SPREAD ? (int)(((tid >> 4) * p.dq_pitch + (tid & 15)) * 4)          // SPREAD: thread = (query tid / 16, d tid % 16)
                                : (int)((l16 * p.dq_pitch + 16 * dqs + 4 * kk) * 4);
@@ -1591,9 +1597,17 @@ mha_bwd8_kernel(const MhaArgs p) {
         if (!sk) return ~0ul;
         int ln = lane;
         asm volatile("" : "+v"(ln));                                            // (once per key block: not worth a register pair held, or spilled, across the tile loop)
-        bytes = ln < nqt ? (int)sk[(long)ln * p.skip_nkb + kb] : 0;
-        if (MASK && p.skip_all && ln < nqt) bytes |= (int)sk[p.skip_all + (long)ln * p.skip_nkb + kb] << 8;   // bits 8..15: "all"
-        const unsigned long any = __builtin_amdgcn_ballot_w64((bytes & 0xff) != 0);
+        bytes = 0;                                                              // per key group kg: bits 16 kg .. "any", 16 kg + 8 .. "all"
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            const int k128 = KG * kb + kg;                                      // the summary's key blocks are 128 keys
+            if (ln < nqt && k128 < p.skip_nkb) {
+                int bb = (int)sk[(long)ln * p.skip_nkb + k128];
+                if (MASK && p.skip_all) bb |= (int)sk[p.skip_all + (long)ln * p.skip_nkb + k128] << 8;
+                bytes |= bb << (16 * kg);
+            }
+        }
+        const unsigned long any = __builtin_amdgcn_ballot_w64((bytes & 0x00ff00ff) != 0);
         return any ? any : 1ul;                                                 // an empty key block still visits tile 0 (all waves idle in it)
     };
     auto first_tile = [&](unsigned long act) -> int { return sk ? __builtin_ctzl(act) : 0; };
@@ -1604,17 +1618,20 @@ mha_bwd8_kernel(const MhaArgs p) {
         return m ? from + __builtin_ctzl(m) : -1;
     };
 
-    float4 vf[NC];                                                              // V[key][16 c + 4 kk + s] * scale of the current key block
+    float4 vf[KG][NC];                                                          // V[key][16 c + 4 kk + s] * scale of the current key block
     auto load_vfrag = [&](int kb) {
-        const int row = kb * 128 + kvl;
 #pragma unroll
-        for (int cc = 0; cc < NC; ++cc) {
-            vf[cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
-            vf[cc].x *= p.scale; vf[cc].y *= p.scale; vf[cc].z *= p.scale; vf[cc].w *= p.scale;
+        for (int kg = 0; kg < KG; ++kg) {
+            const int row = kb * SP + 128 * kg + kvl;
+#pragma unroll
+            for (int cc = 0; cc < NC; ++cc) {
+                vf[kg][cc] = buf_load4(rsrcV, row < p.seq_kv ? (int)((row * p.v_pitch + 16 * cc + 4 * kk) * 4) : OOB);
+                vf[kg][cc].x *= p.scale; vf[kg][cc].y *= p.scale; vf[kg][cc].z *= p.scale; vf[kg][cc].w *= p.scale;
+            }
         }
     };
 
-    int cur_bytes = 0xff, nxt_bytes = 0xff;
+    int cur_bytes = 0x00ff00ff, nxt_bytes = 0x00ff00ff;
     unsigned long act = load_tiles(0, cur_bytes);
     unsigned long written = 0;                                                  // bit qt: some key block has stored dQ rows of tile qt
     dma_group<KPPW>(descK, lds_kb, 0u, vkb);
@@ -1627,7 +1644,7 @@ mha_bwd8_kernel(const MhaArgs p) {
     int j = 0;                                                                  // tiles visited: stage and dS-buffer parity
     int n_inflight = 0;                                                         // vector-memory instructions issued after the last DMA piece
 
-    f32x4 dK[NC], dV[NC], P[2], dS[2];
+    f32x4 dK[KG][NC], dV[KG][NC], P[2], dS[KG][2];
     // ---- dQ^T[d, q] (+)= K^T[d, kv] dS^T[kv, q] of tile `tile` over the 128 keys of the block, from dS buffer `buf`;
     //      `oldq` = what earlier key blocks left there; the DMA pieces of tile `nq` (stage `nstage`) go out inside
     auto dq_phase = [&](int tile, int buf, const f32x4 (&oldq)[DQT]) __attribute__((always_inline)) {
@@ -1652,8 +1669,8 @@ mha_bwd8_kernel(const MhaArgs p) {
 #pragma unroll
             for (int t = 0; t < DQT; ++t) da[0][t] = ld4(tS + rbS[0] + t * SROWS16);
 #pragma unroll
-            for (int cc = 0; cc < 8; ++cc) {
-                if (cc + 1 < 8) {
+            for (int cc = 0; cc < 8 * KG; ++cc) {
+                if (cc + 1 < 8 * KG) {
 #pragma unroll
                     for (int s = 0; s < 4; ++s) ak[(cc + 1) & 1][s] = sKB[wsK[s] + (cc + 1) * ROWS16];
 #pragma unroll
@@ -1681,14 +1698,22 @@ mha_bwd8_kernel(const MhaArgs p) {
     for (int kb = 0; kb < nkb; ++kb) {
         unsigned long act_n = 0;
         if (kb + 1 < nkb) act_n = load_tiles(kb + 1, nxt_bytes);
-        const int kvrow = kb * 128 + kvl;
-        const bool kvok = kvrow < p.seq_kv;
-#pragma unroll
-        for (int t = 0; t < NC; ++t) { dK[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        const int svoff = kvok ? (kvrow + 4 * kk * p.seq_kv) * 4 : OOB;          // saved scores: this lane's key, its rows 4 kk ..
+        int kvrow[KG], svoff[KG], mvoff[KG], kvoob[KG];                         // kvoob: 0, or OOB for a key beyond the sequence (or-ed into store offsets)
+        bool kvok[KG];
         int kkm = kk;
         if (MASK) asm volatile("" : "+v"(kkm));                                  // (the product below once per key block, not a register held across the tile loop)
-        const int mvoff = kvok ? kvrow + 4 * kkm * (int)p.mask_sq : OOB;         // mask bytes, the same way
+#pragma unroll
+        for (int kg = 0; kg < KG; ++kg) {
+            kvrow[kg] = kb * SP + 128 * kg + kvl;
+            kvok[kg] = kvrow[kg] < p.seq_kv;
+            kvoob[kg] = kvok[kg] ? 0 : OOB;
+            if (KG > 1) asm volatile("" : "+v"(kvoob[kg]));                      // (KG = 2: a value, not a condition -- with two conditions hipcc turned the stores below
+                                                                                 //  into exec-masked branches, and the seam's wait counts store instructions)
+#pragma unroll
+            for (int t = 0; t < NC; ++t) { dK[kg][t] = f32x4{0.f, 0.f, 0.f, 0.f}; dV[kg][t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+            svoff[kg] = kvok[kg] ? (kvrow[kg] + 4 * kk * p.seq_kv) * 4 : OOB;    // saved scores: this lane's key, its rows 4 kk ..
+            mvoff[kg] = kvok[kg] ? kvrow[kg] + 4 * kkm * (int)p.mask_sq : OOB;   // mask bytes, the same way
+        }
 
         int pend = -1;                                                           // tile whose dQ product is still to come
         f32x4 pend_old[DQT];
@@ -1706,7 +1731,7 @@ mha_bwd8_kernel(const MhaArgs p) {
             const bool last = nxt < 0;                                           // last tile of this key block
             const int nq = !last ? nxt : (kb + 1 < nkb ? first_tile(act_n) : -1);   // the tile whose Q / dO pieces go out in this one
             // ---- the tile's pieces (and, at a seam, the K block) have landed for every wave; dS of the pending tile is in LDS
-            if (n_inflight == 2 * NC) asm volatile("s_waitcnt vmcnt(%0) ; npm:wait" :: "n"(2 * NC) : "memory");
+            if (n_inflight == 2 * NC * KG) asm volatile("s_waitcnt vmcnt(%0) ; npm:wait" :: "n"(2 * NC * KG) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
@@ -1715,16 +1740,21 @@ mha_bwd8_kernel(const MhaArgs p) {
             const float *tQ = sQ + cur * QTILE, *tDO = sDO + cur * QTILE;
             float *const tDS = sDS + (SPREAD ? 0 : cur * DSBUF);
             const int q0 = 32 * qt;
-            const int tile_bits = sk ? __builtin_amdgcn_readlane(cur_bytes, qt & 63) : 0xff;
-            const bool on = !sk || ((tile_bits >> wave) & 1);                        // this wave's 32 x 16 sub-tile has work
-            //                (written with the `!sk ||`: without it hipcc's allocation of this kernel at D = 128 ends 18 registers
-            //                 higher and spills -- the register file is full here, any change to this kernel needs the metadata test)
-            const bool masked_sub = MASK && !((tile_bits >> (8 + wave)) & 1);        // ... and excluded positions (else: no mask bytes)
+            const int tile_bits = sk ? __builtin_amdgcn_readlane(cur_bytes, qt & 63) : 0x00ff00ff;
+            bool on[KG], masked_sub[KG];
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                on[kg] = !sk || ((tile_bits >> (16 * kg + wave)) & 1);               // this wave's 32 x 16 sub-tile of key group kg has work
+                //            (written with the `!sk ||`: without it hipcc's allocation of this kernel at D = 128 ends 18 registers
+                //             higher and spills -- the register file is full here, any change to this kernel needs the metadata test)
+                masked_sub[kg] = MASK && !((tile_bits >> (16 * kg + 8 + wave)) & 1);  // ... and excluded positions (else: no mask bytes)
+            }
+            const bool any_on = KG == 1 ? on[0] : (on[0] || on[KG - 1]);
 
             // ---- requests of this tile: row terms, raw scores / mask bytes, what earlier key blocks left in its dQ rows
-            f32x4 Lr[2], Dr[2], S[2];
-            unsigned char mk[2][4];
-            if (on) {
+            f32x4 Lr[2], Dr[2], S[KG][2];
+            unsigned char mk[KG][2][4];
+            if (any_on) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) {
                     const u32x4_t l4 = __builtin_amdgcn_raw_buffer_load_b128(rsrcL, 16 * kk, (q0 + 16 * t) * 4, 0);
@@ -1732,19 +1762,23 @@ mha_bwd8_kernel(const MhaArgs p) {
                     Lr[t] = f32x4{__uint_as_float(l4.x), __uint_as_float(l4.y), __uint_as_float(l4.z), __uint_as_float(l4.w)};
                     Dr[t] = f32x4{__uint_as_float(d4.x), __uint_as_float(d4.y), __uint_as_float(d4.z), __uint_as_float(d4.w)};
                 }
+            }
+#pragma unroll
+            for (int kg = 0; kg < KG; ++kg) {
+                if (!on[kg]) continue;
                 if (SAVED) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            S[t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, svoff, (q0 + 16 * t + r) * srow_bytes, 2));
+                            S[kg][t][r] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrcS, svoff[kg], (q0 + 16 * t + r) * srow_bytes, 2));
                 }
-                if (masked_sub) {
+                if (masked_sub[kg]) {
 #pragma unroll
                     for (int t = 0; t < 2; ++t)
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
-                            mk[t][r] = __builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff, (q0 + 16 * t + r) * (int)p.mask_sq, 0);
+                            mk[kg][t][r] = __builtin_amdgcn_raw_buffer_load_b8(rsrcM, mvoff[kg], (q0 + 16 * t + r) * (int)p.mask_sq, 0);
                 }
             }
 
@@ -1769,29 +1803,32 @@ mha_bwd8_kernel(const MhaArgs p) {
             }
             if (sk) written |= 1ul << (qt & 63);
 
-            if (on) {
+#pragma unroll
+          for (int kg = 0; kg < KG; ++kg) {                                  // (KG = 2: the phases below once per key group; the pieces go out in the last)
+            const bool pieces = kg == KG - 1;
+            if (on[kg]) {
                 float4 fa[2][2];
                 if (!SAVED) {
                     // ---- S[q, kv] = Q K^T: NC steps of (3 row reads, 8 MFMAs), reads one step ahead
-                    S[0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[1] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    S[kg][0] = f32x4{0.f, 0.f, 0.f, 0.f}; S[kg][1] = f32x4{0.f, 0.f, 0.f, 0.f};
                     float4 fk[2];
                     fa[0][0] = ld4(tQ + rb[0]);
                     fa[0][1] = ld4(tQ + rb[0] + ROWS16);
-                    fk[0] = ld4(sKW + rb[0]);
+                    fk[0] = ld4(sKW + 128 * kg * D + rb[0]);
 #pragma unroll
                     for (int cc = 0; cc < NC; ++cc) {
                         if (cc + 1 < NC) {
                             fa[(cc + 1) & 1][0] = ld4(tQ + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
                             fa[(cc + 1) & 1][1] = ld4(tQ + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64 + ROWS16);
-                            fk[(cc + 1) & 1] = ld4(sKW + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
+                            fk[(cc + 1) & 1] = ld4(sKW + 128 * kg * D + rb[(cc + 1) & 3] + ((cc + 1) >> 2) * 64);
                         }
                         FENCE();
 #pragma unroll
                         for (int t = 0; t < 2; ++t) {
-                            S[t] = MFMA16(fa[cc & 1][t].x, fk[cc & 1].x, S[t]);
-                            S[t] = MFMA16(fa[cc & 1][t].y, fk[cc & 1].y, S[t]);
-                            S[t] = MFMA16(fa[cc & 1][t].z, fk[cc & 1].z, S[t]);
-                            S[t] = MFMA16(fa[cc & 1][t].w, fk[cc & 1].w, S[t]);
+                            S[kg][t] = MFMA16(fa[cc & 1][t].x, fk[cc & 1].x, S[kg][t]);
+                            S[kg][t] = MFMA16(fa[cc & 1][t].y, fk[cc & 1].y, S[kg][t]);
+                            S[kg][t] = MFMA16(fa[cc & 1][t].z, fk[cc & 1].z, S[kg][t]);
+                            S[kg][t] = MFMA16(fa[cc & 1][t].w, fk[cc & 1].w, S[kg][t]);
                         }
                         FENCE();
                     }
@@ -1811,10 +1848,10 @@ mha_bwd8_kernel(const MhaArgs p) {
                     FENCE();
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
-                        dP[t] = MFMA16(fa[cc & 1][t].x, vf[cc].x, dP[t]);
-                        dP[t] = MFMA16(fa[cc & 1][t].y, vf[cc].y, dP[t]);
-                        dP[t] = MFMA16(fa[cc & 1][t].z, vf[cc].z, dP[t]);
-                        dP[t] = MFMA16(fa[cc & 1][t].w, vf[cc].w, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].x, vf[kg][cc].x, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].y, vf[kg][cc].y, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].z, vf[kg][cc].z, dP[t]);
+                        dP[t] = MFMA16(fa[cc & 1][t].w, vf[kg][cc].w, dP[t]);
                     }
                     FENCE();
                 }
@@ -1824,10 +1861,10 @@ mha_bwd8_kernel(const MhaArgs p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // (an excluded position: score -inf, so P = 0 -- and NaN in a row without any allowed key, see mha_bwd_kernel)
-                        const float pr = fast_exp2(fmaf((masked_sub && mk[t][r] == 0) ? -INFINITY : S[t][r], c, -Lr[t][r]));
+                        const float pr = fast_exp2(fmaf((masked_sub[kg] && mk[kg][t][r] == 0) ? -INFINITY : S[kg][t][r], c, -Lr[t][r]));
                         P[t][r] = pr;
-                        dS[t][r] = pr * dP[t][r];
-                        tDS[wsS[r] + t * SROWS16] = dS[t][r];
+                        dS[kg][t][r] = pr * dP[t][r];
+                        tDS[wsS[r] + t * SROWS16 + 128 * kg] = dS[kg][t][r];
                     }
                 // ---- dV^T[d, kv] += dO^T[d, q] P[q, kv]: 8 steps (4 queries each) of (NV vector reads, NC MFMAs)
                 float ea[2][NV][4];
@@ -1851,11 +1888,11 @@ mha_bwd8_kernel(const MhaArgs p) {
                     // The next tile's Q / dO pieces go out HERE: behind every load whose result this tile still waits for (the
                     // compiler's counted waits do not see them: a wait placed after them would drain them too), a phase and a
                     // half ahead of their use.
-                    if (st == 1 && nq >= 0) issue_q(nq, cur ^ 1);
-                    if (st == 5 && nq >= 0) issue_do(nq, cur ^ 1);
+                    if (pieces && st == 1 && nq >= 0) issue_q(nq, cur ^ 1);
+                    if (pieces && st == 5 && nq >= 0) issue_do(nq, cur ^ 1);
                     FENCE();
 #pragma unroll
-                    for (int x = 0; x < NC; ++x) dV[x] = MFMA16(ea[st & 1][x / VW][x % VW], P[t][r], dV[x]);
+                    for (int x = 0; x < NC; ++x) dV[kg][x] = MFMA16(ea[st & 1][x / VW][x % VW], P[t][r], dV[kg][x]);
                     FENCE();
                 }
                 if constexpr (SPREAD) {
@@ -1883,13 +1920,14 @@ mha_bwd8_kernel(const MhaArgs p) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) tDS[wsS[r] + t * SROWS16] = 0.f;
+                    for (int r = 0; r < 4; ++r) tDS[wsS[r] + t * SROWS16 + 128 * kg] = 0.f;
                 }
-                if (nq >= 0) {
+                if (pieces && nq >= 0) {
                     issue_q(nq, cur ^ 1);
                     issue_do(nq, cur ^ 1);
                 }
             }
+          }
 
             if (last) {
                 // ---- this tile's own dQ product now (the K block is replaced next): dS of all eight key groups must be in LDS
@@ -1900,7 +1938,7 @@ mha_bwd8_kernel(const MhaArgs p) {
                 if (kb + 1 < nkb) {                    // every wave is done with this K block: request the next one
                     __builtin_amdgcn_s_barrier();
                     asm volatile("" ::: "memory");
-                    dma_group<KPPW>(descK, lds_kb, (unsigned)((kb + 1) * 128 * p.k_pitch * 4), vkb);
+                    dma_group<KPPW>(descK, lds_kb, (unsigned)((kb + 1) * SP * p.k_pitch * 4), vkb);
                     load_vfrag(kb + 1);
                 }
                 pend = -1;
@@ -1910,7 +1948,9 @@ mha_bwd8_kernel(const MhaArgs p) {
                 for (int t = 0; t < DQT; ++t) pend_old[t] = own_old[t];
             }
 
-            if (on) {
+#pragma unroll
+          for (int kg = 0; kg < KG; ++kg)
+            if (on[kg]) {
                 // ---- dK^T[d, kv] += Q^T[d, q] dS[q, kv]
                 float ea[2][NV][4];
 #pragma unroll
@@ -1924,7 +1964,7 @@ mha_bwd8_kernel(const MhaArgs p) {
                     }
                     FENCE();
 #pragma unroll
-                    for (int x = 0; x < NC; ++x) dK[x] = MFMA16(ea[st & 1][x / VW][x % VW], dS[t][r], dK[x]);
+                    for (int x = 0; x < NC; ++x) dK[kg][x] = MFMA16(ea[st & 1][x / VW][x % VW], dS[kg][t][r], dK[kg][x]);
                     FENCE();
                 }
             }
@@ -1939,23 +1979,26 @@ mha_bwd8_kernel(const MhaArgs p) {
         // ---- this block's dK and dV rows: lane = key; for a fixed register r the d-tiles of one vector read are VW adjacent
         //      head dimensions, and r = 0 .. 3 continue them: 16 bytes per store
 #pragma unroll
+      for (int kg = 0; kg < KG; ++kg)
+#pragma unroll
         for (int x4 = 0; x4 < (NC + 3) / 4; ++x4)
 #pragma unroll
             for (int r0 = 0; r0 < 4; r0 += 4 / VW) {
                 // d0 = first head dimension of this store: tiles x = 4 x4 .. (VW per register), registers r0 .. r0 + 4 / VW - 1
                 const int d0 = 64 * x4 + VW * (4 * kk + r0);
-                const int offk = kvok ? (int)((kvrow * p.dk_pitch + d0) * 4) : OOB, offv = kvok ? (int)((kvrow * p.dv_pitch + d0) * 4) : OOB;
+                const int offk = KG > 1 ? ((int)((kvrow[kg] * p.dk_pitch + d0) * 4) | kvoob[kg]) : kvok[kg] ? (int)((kvrow[kg] * p.dk_pitch + d0) * 4) : OOB;
+                const int offv = KG > 1 ? ((int)((kvrow[kg] * p.dv_pitch + d0) * 4) | kvoob[kg]) : kvok[kg] ? (int)((kvrow[kg] * p.dv_pitch + d0) * 4) : OOB;
                 float k4[4], v4[4];
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int x = 4 * x4 + e % VW, r = r0 + e / VW;
-                    k4[e] = dK[x < NC ? x : 0][r & 3];
-                    v4[e] = dV[x < NC ? x : 0][r & 3];
+                    k4[e] = dK[kg][x < NC ? x : 0][r & 3];
+                    v4[e] = dV[kg][x < NC ? x : 0][r & 3];
                 }
                 buf_store4(rsrcDK, offk, k4[0], k4[1], k4[2], k4[3]);
                 buf_store4(rsrcDV, offv, v4[0], v4[1], v4[2], v4[3]);
             }
-        n_inflight = 2 * NC;
+        n_inflight = 2 * NC * KG;
         act = act_n;
         cur_bytes = nxt_bytes;
     }
