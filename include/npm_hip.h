@@ -137,7 +137,7 @@ enum {
     NPM_TUNE_GEMM_WAVE_PRIO = 9,     /* s_setprio 3 in the GEMM / conv block prologue (bit 0) and epilogue (bit 1) */
     NPM_TUNE_GEMM_MATH = 10,         /* same as npm_set_math */
     NPM_TUNE_ATTN_STAGGER = 11,      /* attention forward: s_sleep(127) units one of the two blocks of a CU waits at its start (default 1) */
-    NPM_TUNE_CONV_WGRAD_FUSED = 13,  /* npm_conv2d_bwd_w_relu: 1 (default) ReLU backward inside the grad_w kernel, tile height picked; 2 / 3 the same with 128- / 192-row tiles; 0 two passes */
+    NPM_TUNE_CONV_WGRAD_FUSED = 13,  /* npm_conv2d_bwd_w_relu: 1 (default) ReLU backward inside the grad_w kernel, tile height picked (k*k*C0 of exactly three 192-row tiles: one block of twelve waves sharing the masked dy tile); 2 / 3 the same with 128- / 192-row tiles in four-wave blocks; 0 two passes */
     NPM_TUNE_ATTN_BWD16 = 14,        /* attention backward: 2 (default) mha_bwd8_kernel (8 waves on the 16x16x4 MFMA, one barrier per tile, every head size, both score modes, tile skipping) except head size 128 with saved scores and no tile summary, which runs mha_bwd16_kernel; 3 mha_bwd8_kernel always; 1 round 3's choice (mha_bwd16_kernel for head size 128 with saved scores, the 4-wave 32x32x2 kernel otherwise); 0 the 4-wave kernel always */
     NPM_TUNE_KSYNC = 15,             /* K tiles between the soft rendezvous of the co-resident split-K blocks of the fused Conv2D filter gradient: a power of two, default 128; 0 off */
     NPM_TUNE_CONV_KORDER = 16,       /* Conv2D forward / grad_x K loop: 1 (default) the k k taps of one 16-channel chunk back to back (the lines a tap fetched are still in L2 when its neighbour wants them: grad_x of C3 reads 13.8 instead of 82 GB past the L2s, +4 %), 0 taps outermost (kk = tap C + c) */

@@ -505,24 +505,34 @@ struct WgradArgs {
     int tiles_m, tiles_n, splits, k_per_split;
     long slab;
     KSync ksync;         // rendezvous of the co-resident blocks (npm_mfma_tile.h), slice == null: off
+    int parts_m;         // rows of colpart per split: tiles_m, or 1 (TRIO)
 };
 
-template <int WR>
-__global__ void __launch_bounds__(NTHREADS, WR == 3 ? 3 : 4)
+// TRIO (round 5, WR = 3 with exactly three tile rows -- k*k*C0 = 576 at C3): ONE block of twelve waves carries the three tile rows
+// of a (split, column tile) and they share ONE masked dy tile in LDS -- the mask's compares / selects, the dy / pre loads, the g
+// stores and the column sums run once per K tile instead of once per tile row (the three blocks of a split were co-resident and
+// kept in step by the K rendezvous anyway).  Waves 0-7 stage the dense operand (one 16-byte piece of dy and of pre per thread),
+// waves 4 r .. 4 r + 3 gather and multiply tile row r exactly as a block of the four-wave kernel does.
+template <int WR, bool TRIO = false>
+__global__ void __launch_bounds__(TRIO ? 3 * NTHREADS : NTHREADS, TRIO ? 1 : WR == 3 ? 3 : 4)
 conv_wgrad_relu_kernel(const WgradArgs p) {
-    constexpr int TM = 64 * WR, A_TILE = TM * GK, B_TILE = BN * GK, STAGE = A_TILE + B_TILE;
+    constexpr int TM = 64 * WR, A_TILE = TM * GK, B_TILE = BN * GK, STAGE = (TRIO ? 3 : 1) * A_TILE + B_TILE;
     constexpr int PPW = TM / 64;                       // 1 KiB DMA pieces of the gathered tile per wave
     constexpr int CPR = TM / 4;                        // 16-byte chunks per k row of the gathered tile
     constexpr int OOB = 0x7FFFFFFF;
+    static_assert(!TRIO || WR == 3, "three tile rows of 192");
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave_all = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = TRIO ? wave_all & 3 : wave_all;   // within its tile row
+    const int trio_row = TRIO ? wave_all >> 2 : 0;
+    const bool dense = !TRIO || wave_all < 8;          // this wave stages the dense operand (wave-uniform)
     const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
 
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int tiles = p.tiles_m * p.tiles_n;
+    const int tiles = TRIO ? p.tiles_n : p.tiles_m * p.tiles_n;
     const int t = logical % tiles, split = logical / tiles;
-    const int tm = t % p.tiles_m, tn = t / p.tiles_m;  // the tile rows of one (split, tn) are neighbours: they share dy / pre / x in L2
+    const int tm = TRIO ? trio_row : t % p.tiles_m, tn = TRIO ? t : t / p.tiles_m;  // the tile rows of one (split, tn) are neighbours: they share dy / pre / x in L2
     const int m0 = tm * TM, n0 = tn * BN;
     const int kbeg = split * p.k_per_split;
     const int kend = min(p.K, kbeg + p.k_per_split);
@@ -551,7 +561,7 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
         dj[i] = tap - ti * p.ks - p.pad;
         vfast[i] = mq < p.M ? (unsigned)(((kr[i] + halo + di[i] * p.W + dj[i]) * p.C + c) * 4) : (unsigned)OOB;
     }
-    const unsigned lds_a = lds_offset(smem + wave * PPW * 256);
+    const unsigned lds_a = lds_offset(smem + trio_row * A_TILE + wave * PPW * 256);
     // first pixel of the next tile to issue, as (row, column) of its image: scalars
     int w0 = __builtin_amdgcn_readfirstlane(kbeg % p.W), h0 = __builtin_amdgcn_readfirstlane((kbeg / p.W) % p.H);
 
@@ -562,9 +572,9 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
     const auto rsrcPRE = __builtin_amdgcn_make_buffer_rsrc((void *)(p.PRE + (long)kbeg * p.N), 0, (int)(rows_left * p.N * 4), 0x00020000);
     const auto rsrcG = __builtin_amdgcn_make_buffer_rsrc((void *)((p.G ? p.G : p.out) + (long)kbeg * p.N), 0,
                                                          p.G ? (int)(rows_left * p.N * 4) : 0, 0x00020000);
-    const int vb0 = ncol < p.N ? ((tid >> 5) * p.N + ncol) * 4 : OOB;
+    const int vb0 = ncol < p.N ? ((tid >> 5) * p.N + ncol) * 4 : OOB;          // (TRIO: tid < 512, k rows 0 .. 15: one piece per thread)
     const int vb1 = ncol < p.N ? (((tid >> 5) + 8) * p.N + ncol) * 4 : OOB;
-    float *const sBw = smem + A_TILE + (tid >> 5) * BN + 4 * (tid & 31);      // + stage * STAGE (+ 8 BN for the second row)
+    float *const sBw = smem + (TRIO ? 3 : 1) * A_TILE + (tid >> 5) * BN + 4 * (tid & 31);      // + stage * STAGE (+ 8 BN for the second row)
     const int tile_bytes = GK * p.N * 4;
 
     f32x16 acc[WR][2];
@@ -597,15 +607,31 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
         }                                                                                                          \
         w0 += GK;                                                                                                  \
         if (w0 >= p.W) { w0 -= p.W; h0 = h0 + 1 == p.H ? 0 : h0 + 1; }                                             \
-        d0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb0, (KT) * tile_bytes, 0);                             \
-        d1 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb1, (KT) * tile_bytes, 0);                             \
-        q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb0, (KT) * tile_bytes, 0);                            \
-        q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb1, (KT) * tile_bytes, 0);                            \
+        if (!TRIO) {                                                                                               \
+            d0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb0, (KT) * tile_bytes, 0);                         \
+            d1 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb1, (KT) * tile_bytes, 0);                         \
+            q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb0, (KT) * tile_bytes, 0);                        \
+            q1 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb1, (KT) * tile_bytes, 0);                        \
+        } else if (dense) {                                                                                        \
+            d0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcDY, vb0, (KT) * tile_bytes, 0);                         \
+            q0 = __builtin_amdgcn_raw_buffer_load_b128(rsrcPRE, vb0, (KT) * tile_bytes, 0);                        \
+        }                                                                                                          \
     } while (0)
     // mask the dense tile in flight (activations.py:19: x >= 0 keeps dy, x = 0 and -0 included), put it into
     // stage STG; tile row 0 also writes it out as g and adds it to its column sums
 #define NPM_WGRAD_STAGE(KT, STG)                                                                                   \
     do {                                                                                                           \
+        if (TRIO) {                                                                                                \
+            stored = dense;                                                                                        \
+            if (dense) {                                                                                           \
+                const float4 g0 = relu_mask4(q0, d0);                                                              \
+                *reinterpret_cast<float4 *>(sBw + (STG) * STAGE) = g0;                                             \
+                const u32x4 s0 = {__float_as_uint(g0.x), __float_as_uint(g0.y), __float_as_uint(g0.z), __float_as_uint(g0.w)};  \
+                __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcG, vb0, (KT) * tile_bytes, 0);                      \
+                colacc.x += g0.x; colacc.y += g0.y; colacc.z += g0.z; colacc.w += g0.w;                            \
+            }                                                                                                      \
+            break;                                                                                                 \
+        }                                                                                                          \
         const float4 g0 = relu_mask4(q0, d0), g1 = relu_mask4(q1, d1);                                             \
         *reinterpret_cast<float4 *>(sBw + (STG) * STAGE) = g0;                                                     \
         *reinterpret_cast<float4 *>(sBw + (STG) * STAGE + 8 * BN) = g1;                                            \
@@ -628,14 +654,15 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
         /* tile KT is in LDS for every wave (the DMA pieces: vmcnt; the masked rows: lgkmcnt); the other stage is   \
            free.  The g stores of the tile before are this wave's youngest vector-memory operations: they stay in  \
            flight. */                                                                                              \
-        if (stored) asm volatile("s_waitcnt vmcnt(2) ; npm:wait" ::: "memory");                                    \
+        if (TRIO && stored) asm volatile("s_waitcnt vmcnt(1) ; npm:wait" ::: "memory");      /* TRIO: ONE g store */ \
+        else if (stored) asm volatile("s_waitcnt vmcnt(2) ; npm:wait" ::: "memory");                               \
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                                         \
         __builtin_amdgcn_s_barrier();                                                                              \
         asm volatile("" ::: "memory");                                                                             \
         const bool more = (KT) + 1 < nkt;                                                                          \
         if (more) NPM_WGRAD_ISSUE((KT) + 1, (STG) ^ 1);                                                            \
-        const float *sA = smem + (STG) * STAGE, *sB = sA + A_TILE;                                                 \
+        const float *sA = smem + (STG) * STAGE + trio_row * A_TILE, *sB = smem + (STG) * STAGE + (TRIO ? 3 : 1) * A_TILE;   \
         _Pragma("unroll") for (int g = 0; g < GK / 8; ++g) {                                                       \
             float4 a[WR], b[2];                                                                                    \
             _Pragma("unroll") for (int i = 0; i < WR; ++i) a[i] = read_frag16<false, TM>(sA, arow + 32 * i, g, half);   \
@@ -680,14 +707,15 @@ conv_wgrad_relu_kernel(const WgradArgs p) {
     }
     // ---- column sums of g over this split's pixels: the 8 k-row groups of the block through LDS, fixed order
     if (p.colpart) {
+        constexpr int KROWS = TRIO ? 16 : 8;            // k-row groups of the block's dense staging
         __syncthreads();                                // every wave is done with the operand stages
-        *reinterpret_cast<float4 *>(smem + (tid >> 5) * BN + 4 * (tid & 31)) = colacc;
+        if (dense) *reinterpret_cast<float4 *>(smem + (tid >> 5) * BN + 4 * (tid & 31)) = colacc;
         __syncthreads();
         if (tid < BN) {
             float total = 0.f;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) total += smem[r * BN + tid];
-            if (n0 + tid < p.N) p.colpart[((long)split * p.tiles_m + tm) * p.N + n0 + tid] = total;
+            for (int r = 0; r < KROWS; ++r) total += smem[r * BN + tid];
+            if (n0 + tid < p.N) p.colpart[((long)split * p.parts_m + (TRIO ? 0 : tm)) * p.N + n0 + tid] = total;
         }
     }
 }
@@ -711,7 +739,7 @@ int g_conv_dma = 1;     // tuning knob NPM_TUNE_CONV_DMA
 int g_conv_wave_prio = 0;   // NPM_TUNE_GEMM_WAVE_PRIO
 int g_conv_math = 0;        // NPM_TUNE_GEMM_MATH
 int g_conv_korder = 1;      // NPM_TUNE_CONV_KORDER: 1 (default) 16-channel chunks outermost, 0 taps outermost
-int g_wgrad_fused = 1;           // NPM_TUNE_CONV_WGRAD_FUSED: 0 two passes (ReLU backward, then grad_w), 1 fused (tile height picked), 2 / 3 fused with 128- / 192-row tiles
+int g_wgrad_fused = 1;           // NPM_TUNE_CONV_WGRAD_FUSED: 0 two passes (ReLU backward, then grad_w), 1 fused (tile height picked; three tile rows of 192: one block of twelve waves), 2 / 3 fused with 128- / 192-row tiles in four-wave blocks
 int g_wgrad_blocks_per_cu = 0;   // NPM_TUNE_CONV_WGRAD_BLOCKS: 0 pick_splits chooses 3 or 4 blocks per CU, 3 / 4 pins it, -1 the old ceil(3 CUs / tiles)
 
 int run_conv_gemm(const float *x, const float *filt_kn, int nb, int h, int w, int c, int n_out, int ks,
@@ -910,8 +938,11 @@ int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, flo
         const bool fits = ((long)a.k_per_split + 2 * halo + GK) * c_in * 4 < (1L << 30) && (long)a.k_per_split * c_out * 4 < (1L << 30) &&
                           tiles * splits < (1L << 31);
         if (fits) {
+            // TRIO: the three tile rows of a split in one block of twelve waves (NPM_TUNE_CONV_WGRAD_FUSED = 3 keeps the four-wave blocks)
+            const bool trio = tall && a.tiles_m == 3 && splits > 1 && g_wgrad_fused != 3;
+            a.parts_m = trio ? 1 : a.tiles_m;
             npm::Scratch ws, parts;
-            int rc = parts.alloc(sizeof(float) * (size_t)splits * a.tiles_m * c_out);
+            int rc = parts.alloc(sizeof(float) * (size_t)splits * a.parts_m * c_out);
             if (rc) return rc;
             a.colpart = (float *)parts.ptr;
             a.slab = (long)m * c_out;
@@ -924,14 +955,15 @@ int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, flo
             }
             hipStream_t s = npm::ctx().stream;
             npm::note_math(0);
-            const int grid = (int)(tiles * splits);
+            const int grid = (int)((trio ? a.tiles_n : tiles) * splits);
             // K rendezvous: all blocks resident at once (3 or 4 per CU), every split long enough
-            if (splits > 1 && grid <= (long)resident * npm::ctx().num_cus && npm::ksync_every() > 0 && kt_per >= 2 * npm::ksync_every()) {
+            if (!trio && splits > 1 && grid <= (long)resident * npm::ctx().num_cus && npm::ksync_every() > 0 && kt_per >= 2 * npm::ksync_every()) {
                 a.ksync.slice = npm::ksync_slice();
                 a.ksync.every = npm::ksync_every();
                 a.ksync.epochs = (nkt - (splits - 1) * kt_per - 1) / a.ksync.every;
             }
-            if (tall) hipLaunchKernelGGL(conv_wgrad_relu_kernel<3>, dim3(grid), dim3(NTHREADS), 0, s, a);
+            if (trio) hipLaunchKernelGGL((conv_wgrad_relu_kernel<3, true>), dim3(grid), dim3(3 * NTHREADS), 0, s, a);
+            else if (tall) hipLaunchKernelGGL(conv_wgrad_relu_kernel<3>, dim3(grid), dim3(NTHREADS), 0, s, a);
             else hipLaunchKernelGGL(conv_wgrad_relu_kernel<2>, dim3(grid), dim3(NTHREADS), 0, s, a);
             NPM_CHECK_LAUNCH();
             if (splits > 1) {
@@ -942,7 +974,7 @@ int npm_conv2d_bwd_w_relu(const float *dy, const float *pre, const float *x, flo
                 rc = launch_splitk_reduce(r, s);
                 if (rc) return rc;
             }
-            return npm_colsum(a.colpart, db, (int64_t)splits * a.tiles_m, c_out, c_out);       // fixed order over the partial rows
+            return npm_colsum(a.colpart, db, (int64_t)splits * a.parts_m, c_out, c_out);       // fixed order over the partial rows
         }
     }
     int rc = npm_relu_bwd_colsum(pre, dy, g, db, pixels, c_out);

@@ -176,18 +176,63 @@ def test_conv_bwd_w_relu_rendezvous_changes_nothing(npm):
             src = np.ascontiguousarray(src)                  # (kept alive across the copy)
             _C.check(lib.npm_h2d(dst.ptr + 4 * i * src.size, src.ctypes.data, 4 * src.size))
     runs = {}
-    for every in (0, 128, 32):
-        _C.check(lib.npm_set_tuning(15, every))
-        try:
-            g, dw, db = D.empty([n, h, w, c1]), D.empty([k, k, c0, c1]), D.empty([c1])
-            _C.check(lib.npm_conv2d_bwd_w_relu(dy.ptr, pre.ptr, x.ptr, g.ptr, dw.ptr, db.ptr, n, h, w, c0, c1, k))
-            runs[every] = (dw.numpy().copy(), db.numpy().copy(), g.numpy()[::5, ::37, ::41].copy())
-        finally:
-            _C.check(lib.npm_set_tuning(15, 128))
+    _C.check(lib.npm_set_tuning(13, 3))                      # the four-wave kernel, three blocks per split (the default at this shape
+    try:                                                     # is one block of twelve waves, which needs no rendezvous: next test)
+        for every in (0, 128, 32):
+            _C.check(lib.npm_set_tuning(15, every))
+            try:
+                g, dw, db = D.empty([n, h, w, c1]), D.empty([k, k, c0, c1]), D.empty([c1])
+                _C.check(lib.npm_conv2d_bwd_w_relu(dy.ptr, pre.ptr, x.ptr, g.ptr, dw.ptr, db.ptr, n, h, w, c0, c1, k))
+                runs[every] = (dw.numpy().copy(), db.numpy().copy(), g.numpy()[::5, ::37, ::41].copy())
+            finally:
+                _C.check(lib.npm_set_tuning(15, 128))
+    finally:
+        _C.check(lib.npm_set_tuning(13, 1))
     for every in (128, 32):
         for got, want in zip(runs[every], runs[0]):
             np.testing.assert_array_equal(got, want)
     assert np.isfinite(runs[0][0]).all() and np.abs(runs[0][0]).max() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,h,w', [(4, 64, 64), (3, 40, 48), (16, 128, 128)])
+def test_conv_bwd_w_relu_twelve_wave_block_equals_three_blocks(npm, n, h, w):
+    """k*k*C0 = 576 (C3's filter: three tile rows of 192): by default ONE block of twelve waves carries the three tile rows of a
+    split and they share one masked dy tile (conv_wgrad_relu_kernel<3, true>); NPM_TUNE_CONV_WGRAD_FUSED = 3 runs the three
+    four-wave blocks of rounds 3-4.  Same products in the same order: dw and g are bit-equal; db is summed in another grouping
+    (16 k-row groups per block against 8 per tile row with turns) and agrees to rounding; all three match the elementwise /
+    NumPy reference.  Includes a pixel count whose splits are uneven and borders on every tile."""
+    from np_modeling_amd import _C, device as D
+    lib = _C.lib()
+    c0, c1, k = 64, 128, 3
+    rng = np.random.default_rng(n * h + w)
+    xh = rng.standard_normal([n, h, w, c0]).astype(np.float32)
+    dyh = rng.standard_normal([n, h, w, c1]).astype(np.float32)
+    preh = rng.standard_normal([n, h, w, c1]).astype(np.float32)
+    preh[0, 0, :8, :4] = np.array([0.0, -0.0, 1e-30, -1e-30], dtype=np.float32)      # the mask is x >= 0, +-0 included
+    x, dy, pre = D.from_host(xh), D.from_host(dyh), D.from_host(preh)
+    runs = {}
+    for mode in (1, 3):
+        _C.check(lib.npm_set_tuning(13, mode))
+        try:
+            g, dw, db = D.full([n, h, w, c1], 7.0), D.empty([k, k, c0, c1]), D.empty([c1])
+            _C.check(lib.npm_conv2d_bwd_w_relu(dy.ptr, pre.ptr, x.ptr, g.ptr, dw.ptr, db.ptr, n, h, w, c0, c1, k))
+            runs[mode] = (dw.numpy().copy(), g.numpy().copy(), db.numpy().copy())
+        finally:
+            _C.check(lib.npm_set_tuning(13, 1))
+    np.testing.assert_array_equal(runs[1][0], runs[3][0])
+    np.testing.assert_array_equal(runs[1][1], runs[3][1])
+    gref = np.where(preh >= 0, dyh, np.float32(0))
+    np.testing.assert_array_equal(runs[1][1], gref)
+    dbref = gref.astype(np.float64).sum(axis=(0, 1, 2))
+    for mode in (1, 3):
+        assert np.abs(runs[mode][2] - dbref).max() <= 1e-5 * np.abs(dbref).max() + 1e-4
+    # dw against fp64 on a few filter taps (the whole product is test_conv_bwd_w_relu's business)
+    xp = np.pad(xh.astype(np.float64), ((0, 0), (1, 1), (1, 1), (0, 0)))
+    for (ti, tj) in ((0, 0), (1, 1), (2, 1)):
+        want = np.einsum('nhwc,nhwd->cd', xp[:, ti:ti + h, tj:tj + w, :], gref.astype(np.float64))
+        got = runs[1][0][ti, tj]
+        assert np.abs(got - want).max() <= 2e-5 * np.abs(want).max()
 
 
 def test_conv_rejects_even_kernel(npm):
