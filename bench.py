@@ -125,6 +125,24 @@ def cpu_baseline(args, params):
     return out
 
 
+ALT_MATH_LINES = (('alt_math', 'bf16x3'), ('alt_math_f16x2', 'f16x2'))
+
+
+def reported_math_modes():
+    """The arithmetics this file reports a throughput line for: the headline's and one per ALT_MATH_LINES entry -- only modes
+    with a parity bound in include/npm_hip.h (NPM_PARITY_*), which tests/test_gpu_parity.py asserts on every BASELINE config."""
+    from np_modeling_amd import _C
+    bounds = _C.parity_bounds()
+    return [m for m in ['f32'] + [mode for _, mode in ALT_MATH_LINES] if m in bounds]
+
+
+def parity_note(mode):
+    from np_modeling_amd import _C
+    rel, scaled = _C.parity_bounds()[mode]
+    return {'rel_bound': rel, 'scaled_bound': scaled, 'source': f'include/npm_hip.h NPM_PARITY_*_{mode.upper()}',
+            'asserted_by': f'tests/test_gpu_parity.py::test_baseline_configs_meet_the_stated_bound[{mode}] (C1-C5 at full width vs the fp64 oracle)'}
+
+
 def alt_roofline(timer, per_product=6, kernel=None):
     """Kernel-level roofline of a split-precision GEMM family against the 16-bit MFMA peak: every fp32 product is
     executed as `per_product` v_mfma_f32_32x32x16 (bf16 split: 6, scaled fp16 split: 3), so the pipe executes that
@@ -387,7 +405,8 @@ def main():
                            'steps': args.steps, 'step_tflops_per_gpu': alt_value / world * fps / 1e12,
                            'step_frac_of_fp32_mfma_peak': alt_value / world * fps / 1e12 / FP32_MFMA_PEAK_TFLOPS}
 
-    if args.math == 'f32' and not args.no_alt_math:
+    result['parity'] = parity_note(args.math) if args.math in reported_math_modes() else None
+    if args.math == 'f32' and not args.no_alt_math and 'bf16x3' in reported_math_modes():
         # the matrix products on the bf16 pipe (three-way operand split, fp32-class error -- DESIGN.md 4.1,
         # tests/test_gpu_gemm.py::test_split_math_error_statistics)
         alt_timer, obj = alt_region('bf16x3')
@@ -398,7 +417,9 @@ def main():
                     'each product formed from three-way bf16 splits of both operands (six v_mfma_f32_32x32x16_bf16); '
                     'rms error vs fp64 at or below the exact-f32 MFMA path (profiles/r02_math_error.log). '
                     'Not the headline: value above is the exact-f32 MFMA path.'})
+        obj['parity'] = parity_note('bf16x3')
         result['alt_math'] = obj
+    if args.math == 'f32' and not args.no_alt_math and 'f16x2' in reported_math_modes():
         # ... and on the f16 pipe: two-way fp16 split with row scaling, three MFMAs per product (csrc/npm_gemm_f16x2.hip)
         alt_timer, obj = alt_region('f16x2')
         obj.update({
@@ -409,6 +430,7 @@ def main():
                     'scaled by a power of two, split into two fp16 parts, (hi hi + hi lo + lo hi) / (s_a s_b); error against '
                     'fp64 below a k-ordered fp32 fma chain ROW-NORMWISE (profiles/r02_f16x2_gemm.log), not elementwise. '
                     'Not the headline: value above is the exact-f32 MFMA path.'})
+        obj['parity'] = parity_note('f16x2')
         result['alt_math_f16x2'] = obj
     if world == 1 and not args.no_configs and args.math == 'f32':
         # The other single-GPU configurations of BASELINE.json at full size, same process, after the headline regions

@@ -171,6 +171,9 @@ _COMM_SPECIAL = {'npm_comm_last_error': (C.c_char_p, [])}
 _LIB: Optional[object] = None       # the loaded library (tests may install a host simulator here)
 _COMM_LIB: Optional[object] = None
 _DEVICE: Optional[int] = None
+# Set by device.UpdateQueue while it holds queued parameter updates: called by lib() in front of every library call that
+# is not itself part of the queue, so a launch issued between two queued updates sees them applied (program order).
+_ORDER_HOOK = None
 
 
 def _bind(cdll, signatures, special):
@@ -263,12 +266,17 @@ def library_is_current() -> bool:
     return all(os.path.getmtime(p) <= built for p in sources)
 
 
-def lib():
-    """The bound, device-initialised library.  Raises if there is no library or no GPU."""
+def lib(ordered: bool = True):
+    """The bound, device-initialised library.  Raises if there is no library or no GPU.  ``ordered=False``: the caller
+    touches nothing a queued parameter update reads or writes (device.UpdateQueue) and need not wait for the queue."""
     global _LIB, _DEVICE
+    if ordered and _ORDER_HOOK is not None:
+        _ORDER_HOOK()
     if _LIB is None:
+        ipc_env_for_multi_rank()
         _LIB = load_library()
     if _DEVICE is None:
+        ipc_env_for_multi_rank()
         count = C.c_int(0)
         _LIB.npm_device_count(C.byref(count))         # 0 devices: npm_init below reports it with the HIP error text
         device = pick_device(count.value, os.environ)
@@ -284,6 +292,19 @@ def lib():
         if os.environ.get('NPM_MATH'):
             set_math(os.environ['NPM_MATH'])
     return _LIB
+
+
+def ipc_env_for_multi_rank(env=None) -> bool:
+    """One rank of several: RCCL shares device buffers between the processes of a node, and this pool's host driver only
+    supports dmabuf IPC -- without ``HSA_ENABLE_IPC_MODE_LEGACY=0`` it fails with ``hipIpcGetMemHandle: invalid argument``.
+    The runtime reads the variable when it initialises, so it is set (unless the user chose a value) before the device
+    library is loaded / initialised, whoever launched the ranks (np_modeling_amd/launch.py exports it too).  Returns
+    whether this process is one of several ranks."""
+    env = os.environ if env is None else env
+    if int(env.get('WORLD_SIZE', '1') or '1') <= 1:
+        return False
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    return True
 
 
 def pick_device(visible: int, env) -> int:
@@ -306,6 +327,22 @@ def pick_device(visible: int, env) -> int:
 
 
 MATH_MODES = {'f32': 0, 'bf16x3_fast': 1, 'bf16x3': 2, 'f16x2': 3}      # include/npm_hip.h NPM_MATH_*
+
+
+def parity_bounds() -> dict:
+    """{mode: (REL, SCALED)} -- the parity contract of each math mode as include/npm_hip.h states it (NPM_PARITY_*): the
+    header is the one place the numbers live; tests/test_gpu_parity.py asserts them and bench.py reports a throughput line
+    only for a mode that has them."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, 'include', 'npm_hip.h')) as f:
+        found = dict(re.findall(r'#define\s+NPM_PARITY_(\w+)\s+([0-9.eE+-]+)', f.read()))
+    out = {}
+    for mode in MATH_MODES:
+        rel, scaled = found.get('REL_' + mode.upper()), found.get('SCALED_' + mode.upper())
+        if rel is not None and scaled is not None:
+            out[mode] = (float(rel), float(scaled))
+    return out
 
 
 def current_math() -> str:

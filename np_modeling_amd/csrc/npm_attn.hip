@@ -2355,8 +2355,10 @@ extern "C" int npm_mha_core_bwd(const npm_mha_core *c) {
         rc = ws.alloc(sizeof(float) * 2 * (size_t)padded);
         if (rc) return rc;
         a.lse2 = (float *)ws.ptr + padded;
-        if (c->neg_delta != nullptr) {
-            // the caller computed MINUS scale * (dctx_i . ctx_i) where dctx was produced (NPM_EPI_ROWDOT): no pass over dctx and ctx
+        if (c->neg_delta != nullptr && a.seq_q % 4 == 0) {
+            // the caller computed MINUS scale * (dctx_i . ctx_i) where dctx was produced (NPM_EPI_ROWDOT): no pass over dctx and ctx.
+            // The kernels fetch four row terms per 16-byte load: rows of seq_q % 4 != 0 floats are not aligned for that, and
+            // such a call recomputes the terms into the padded scratch below like a call without neg_delta.
             NPM_ARG(c->neg_delta_stride_b >= 0 && c->neg_delta_stride_h >= 0 && al16(c->neg_delta) &&
                     c->neg_delta_stride_b % 4 == 0 && c->neg_delta_stride_h % 4 == 0);
             a.delta = const_cast<float *>(c->neg_delta);

@@ -40,7 +40,7 @@ class _Buffer:
     __slots__ = ('ptr', 'nbytes', '__weakref__')
 
     def __init__(self, nbytes: int):
-        lib = _C.lib()
+        lib = _C.lib(ordered=False)              # an allocation reads and writes no array
         out = C.c_void_p()
         _C.check(lib.npm_malloc(C.byref(out), max(int(nbytes), 4)), 'npm_malloc')
         self.ptr = out.value
@@ -421,27 +421,52 @@ class UpdateQueue:
     mirrors it -- run as one launch over the joined range.  The optimizer is not involved: the reference's unchanged
     ``SGDOptimizer.update_variable`` (``variable -= lr * gradient``, optimizer.py:32) reaches ``DeviceArray._axpy``
     exactly as before, once per ``Optimizer.update(obj, attribute, grad)``, with its ``id(obj).attribute`` keying.
-    Elementwise updates do not care where a range is cut: results are bit-identical to the per-parameter launches."""
+    Elementwise updates do not care where a range is cut: results are bit-identical to the per-parameter launches.
+
+    Program order is kept for everything an observer can tell apart (any ``Optimizer`` subclass may run in here, not only
+    the shipped ones): queued updates are launched sorted by address, so only updates that touch DISJOINT memory wait in
+    the queue together -- one that writes what a queued one reads or writes, or reads what a queued one writes (weight
+    decay after the step, a momentum buffer updated and then applied), first drains the queue; and so does every library
+    call that is not part of the queue (``*=``, ``numpy()``, ``set``, any kernel: ``_C.lib()`` calls ``_C._ORDER_HOOK``)."""
 
     active: Optional['UpdateQueue'] = None
 
     def __init__(self):
         self._pending = []
+        self._keep = []
         self.launches = 0        # kernels launched by run()
         self.updates = 0         # updates they stand for
+        self.drains = 0          # times the queue was emptied early to keep program order
+
+    def _enqueue(self, item: '_Pending') -> None:
+        def overlap(a_lo, a_n, b_lo, b_n):
+            return a_lo < b_lo + 4 * b_n and b_lo < a_lo + 4 * a_n
+        for p in self._pending:
+            if overlap(item.var, item.n, p.var, p.n) or overlap(item.var, item.n, p.grad, p.n) or overlap(item.grad, item.n, p.var, p.n):
+                self.drains += 1
+                self.run()
+                break
+        self._pending.append(item)
+        _C._ORDER_HOOK = self._drain
+
+    def _drain(self) -> None:
+        if self._pending:
+            self.drains += 1
+            self.run()
 
     def axpy(self, var: 'DeviceArray', grad: 'DeviceArray', alpha: float) -> None:
-        self._pending.append(_Pending(var.ptr, grad.ptr, var.size, ('axpy', alpha), var._buf, grad._buf))
+        self._keep.append(grad)                     # a temporary (``lr * host_array``) must outlive the deferred launch
+        self._enqueue(_Pending(var.ptr, grad.ptr, var.size, ('axpy', alpha), var._buf, grad._buf))
 
     def adam(self, var: 'DeviceArray', grad: 'DeviceArray', first_ptr: int, second_ptr: int, hyper: tuple, owner) -> None:
         """``hyper`` = (lr, beta1, beta2, epsilon, step); ``owner`` keeps the moment buffers alive until run()."""
-        self._pending.append(_Pending(var.ptr, grad.ptr, var.size, ('adam',) + tuple(hyper), var._buf, grad._buf,
-                                      ((first_ptr, 8), (second_ptr, 8))))
-        self._keep = getattr(self, '_keep', [])
-        self._keep.append(owner)
+        self._keep += [owner, grad]
+        self._enqueue(_Pending(var.ptr, grad.ptr, var.size, ('adam',) + tuple(hyper), var._buf, grad._buf,
+                               ((first_ptr, 8), (second_ptr, 8))))
 
     def run(self) -> None:
-        lib = _C.lib()
+        _C._ORDER_HOOK = None                       # the launches below are the queue itself
+        lib = _C.lib(ordered=False)
         pending, self._pending = sorted(self._pending, key=lambda u: (u.key[0], u.var)), []
         self.updates += len(pending)
         run: Optional[_Pending] = None
@@ -473,6 +498,7 @@ class coalesced_updates:
     def __exit__(self, exc_type, exc, tb) -> bool:
         if self._mine:
             queue, UpdateQueue.active = UpdateQueue.active, None
+            _C._ORDER_HOOK = None
             if exc_type is None:
                 queue.run()
         return False

@@ -75,6 +75,11 @@ class Layer(abc.ABC):
         no outside alias of a parameter can be stale afterwards: from ``initialize`` or at the end of the first forward."""
         if D.COALESCE_UPDATES:
             self._arena = D.ParamArena(segments)
+            # a sub-layer whose parameters all moved here would keep its own (now dead) arena block alive -- a second copy
+            # of every parameter, deep-copied along with the layer
+            for obj in {id(o): o for segment in segments for o, _ in segment}.values():
+                if obj is not self and obj._arena is not None and not obj._arena.live():
+                    obj._arena = None
 
     def _param(self, attribute: str) -> D.DeviceArray:
         """Current value of a parameter as a DeviceArray.  Tests and weight binders assign arbitrary array-likes

@@ -62,7 +62,7 @@ class _BlockMoments:
         self.count = max(block.nbytes // 4, 1)
         self.first, self.second = D._Buffer(8 * self.count), D._Buffer(8 * self.count)
         for buf in (self.first, self.second):
-            _C.check(_C.lib().npm_fill_f64(buf.ptr, 0.0, self.count), 'npm_fill_f64')
+            _C.check(_C.lib(ordered=False).npm_fill_f64(buf.ptr, 0.0, self.count), 'npm_fill_f64')       # fresh buffers: no queued update touches them
 
 
 class _DeviceMoments:

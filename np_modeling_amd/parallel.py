@@ -145,8 +145,8 @@ def _launch_token() -> str:
     * an explicitly named ``NPM_RENDEZVOUS_FILE`` with a job id in the environment (torch.distributed.run's run id, the SLURM
       job id): job id + ``MASTER_ADDR:MASTER_PORT`` + the agent's restart count -- the same for every rank of the job whoever
       its parent process is, different for a later job;
-    * an explicitly named file WITHOUT either, shared by ranks that are not all on this node (``WORLD_SIZE != LOCAL_WORLD_SIZE``):
-      an error -- nothing in the environment tells this launch from an earlier one with the same address (round 4 used the
+    * an explicitly named file WITHOUT either, shared by ranks that are not known to be siblings on this node (``LOCAL_WORLD_SIZE``
+      unset or ``!= WORLD_SIZE``): an immediate error -- nothing in the environment tells this launch from an earlier one with the same address (round 4 used the
       address alone: a stale file then passed for a fresh one and ranks other than 0 could hand a dead id to ncclCommInitRank);
     * otherwise the ranks of a node are children of one launcher process (torch.distributed.run's agent, a shell): its pid
       plus its start time (field 22 of /proc/<pid>/stat; pids are recycled, start times are not) plus the restart count."""
@@ -159,8 +159,10 @@ def _launch_token() -> str:
         if job:
             return f'{job}-{os.environ.get("MASTER_ADDR", "")}:{os.environ.get("MASTER_PORT", "")}-{restart}'
         world, local_world = os.environ.get('WORLD_SIZE', '1'), os.environ.get('LOCAL_WORLD_SIZE')
-        if local_world and local_world != world:
-            raise _C.NpmError('NPM_RENDEZVOUS_FILE is shared by ranks that are not children of one launcher (WORLD_SIZE='
+        if int(world) > 1 and local_world != world:
+            # LOCAL_WORLD_SIZE absent: nothing says the ranks are siblings (separate shells, several nodes) -- their parent
+            # pids would differ and every rank but 0 would poll until the timeout instead of failing here
+            raise _C.NpmError('NPM_RENDEZVOUS_FILE is shared by ranks that are not known to be children of one launcher (WORLD_SIZE='
                               f'{world}, LOCAL_WORLD_SIZE={local_world}) and nothing identifies this launch: set NPM_LAUNCH_TOKEN '
                               'to a value that is new for every job (or run under a launcher that exports TORCHELASTIC_RUN_ID '
                               'or SLURM_JOB_ID); MASTER_ADDR:MASTER_PORT alone cannot tell a stale file from a fresh one')
@@ -279,6 +281,7 @@ def init(reduce: str = 'avg') -> Communicator:
         _COMM = Communicator()
         return _COMM
     global PLACEMENT
+    _C.ipc_env_for_multi_rank()                          # before the device library initialises the runtime (external launchers)
     if world > 1:
         # one rank of several on this node: die with the launcher, and run on the CPUs of the GPU's own NUMA node --
         # both before anything touches the device (the driver's threads inherit the mask)

@@ -51,7 +51,7 @@ def fwd_kernel(request, npm):
     _C.check(_C.lib().npm_set_tuning(17, 2), 'npm_set_tuning')
 
 
-def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=False, lse_ctx=None, skip=True):
+def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=False, lse_ctx=None, skip=True, neg_delta=None):
     """q [B,Sq,H,D], k/v [B,Skv,H,D] host arrays -> dict of host results from the C ABI.  ``packed``: q, k, v
     live in one [B, S, 3, H, D] buffer (row pitch 3 H D), like the layer's packed projection."""
     from np_modeling_amd import _C, device as D
@@ -116,6 +116,9 @@ def _run_core(npm, q, k, v, scale, dctx=None, mask=None, save=False, packed=Fals
         c.dctx, c.dctx_pitch = dctx_d.ptr, h * d
         c.dq, c.dk, c.dv = (x.ptr for x in views)
         c.dq_pitch, c.dk_pitch, c.dv_pitch = gp
+        if neg_delta is not None:                               # [H, B, Sq] row terms taken by the caller (include/npm_hip.h)
+            nd = D.from_host(neg_delta)
+            c.neg_delta, c.neg_delta_stride_b, c.neg_delta_stride_h = nd.ptr, neg_delta.shape[2], neg_delta.shape[1] * neg_delta.shape[2]
         _C.check(lib.npm_mha_core_bwd(C.byref(c)), 'npm_mha_core_bwd')
         if packed:
             raw = gbuf.numpy()
@@ -185,6 +188,33 @@ def test_core_saved_scores_head_128(npm, b, h, sq, skv, bwd_kernel):
     assert_close(got['scores'], np.einsum('bqhd,bkhd->bhqk', q64, k64), tol=2e-6)
     for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
         assert_close(got[name], want, tol=3e-6, what=f'{name} bwd16={bwd16}')
+
+
+@pytest.mark.parametrize('b,h,sq,skv,d', [(2, 2, 64, 64, 128), (1, 3, 200, 130, 128), (2, 2, 36, 70, 64), (1, 2, 128, 96, 32),
+                                           (2, 1, 33, 47, 128), (1, 2, 130, 64, 16), (1, 1, 7, 9, 64)])
+def test_core_row_terms_from_the_caller(npm, b, h, sq, skv, d, bwd_kernel):
+    """``npm_mha_core.neg_delta``: MINUS scale * (dctx_i . ctx_i) handed in by the caller (the layer takes it from the GEMM that
+    produces dctx).  Any head size on the eight-wave kernels; a sequence length that is not a multiple of 4 (rows not aligned
+    for the kernels' 16-byte row-term loads) and the four-wave kernels recompute the terms instead -- same results either way.
+    The terms handed in are deliberately the EXACT ones: a kernel that ignored the pointer where it should not would still
+    pass, so a second run with WRONG terms must change dq exactly where the pointer is honoured."""
+    rng = np.random.default_rng(b * 77 + sq * 5 + skv + d)
+    q = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    k = rng.standard_normal([b, skv, h, d]).astype(np.float32)
+    v = rng.standard_normal([b, skv, h, d]).astype(np.float32)
+    dctx = rng.standard_normal([b, sq, h, d]).astype(np.float32)
+    scale = 1.0 / np.sqrt(d)
+    q64, k64, v64, d64 = (x.astype(np.float64) for x in (q, k, v, dctx))
+    ctx, lse, probs = O.attention_core_fwd(q64, k64, v64, scale)
+    dq, dk, dv = O.attention_core_bwd(q64, k64, v64, probs, d64, scale)
+    terms = -scale * np.einsum('bqhd,bqhd->hbq', d64, ctx)
+    got = _run_core(npm, q, k, v, scale, dctx=dctx, save=d >= 64, lse_ctx=(lse, ctx), neg_delta=terms.astype(np.float32))
+    for name, want in (('dq', dq), ('dk', dk), ('dv', dv)):
+        assert_close(got[name], want, tol=3e-6, what=name)
+    wrong = _run_core(npm, q, k, v, scale, dctx=dctx, save=d >= 64, lse_ctx=(lse, ctx), neg_delta=(terms + 1.0).astype(np.float32))
+    honoured = bwd_kernel != 0 and sq % 4 == 0 and not (bwd_kernel == 1 and d != 128)
+    assert (np.abs(wrong['dq'] - got['dq']).max() > 1e-3) == honoured
+    assert_close(wrong['dv'], dv, tol=3e-6)                      # dV = P^T dctx does not involve the row terms
 
 
 @pytest.mark.parametrize('b,h,s,d', [(2, 4, 96, 16), (1, 8, 160, 128), (2, 2, 64, 64)])

@@ -498,3 +498,92 @@ def test_decoder_slice(npm, norm_first):
             assert np.abs(a).max() < 1e-4 * bq_scale and np.abs(c2).max() < 1e-4 * bq_scale
             continue
         assert_close(a, c2, tol=1e-5, what=str(k[:2]))
+
+
+# ---- weight gradients at BASELINE's FULL contraction length, against fp64 directly ------------------------------------
+# The additivity checks above compare the kernels with themselves; the tests below hold the SHIPPED split-K path (split
+# counts, slab reduction, fused bias sums) against the oracle's arithmetic in fp64 at the real K: dw = x^T dy with
+# K = B S = 131 072 (reference layers/mlp.py:34-35, layers/attentions.py:167-188) and Conv2D's filter gradient with
+# K = 256 x 224 x 224 = 12.8 M pixels (layers/conv.py:54-56,185-194).  The fp64 side runs in chunks over K (bounded host
+# memory); tolerance: the GEMM tests' metric, |got - ref| <= tol (|ref| + max |ref|).
+FULL_K_TOL = {'f32': 2e-6, 'bf16x3': 2e-6, 'f16x2': 2e-6}
+
+
+@pytest.mark.parametrize('m,n,which', [(1024, 4096, 'bsum'), (4096, 1024, 'bsum'), (3072, 1024, 'asum'), (1024, 1024, 'asum')])
+def test_weight_gradient_gemm_at_full_k_against_fp64(npm, exact_modes, m, n, which):
+    """npm_sgemm TN at (M, N, K) = the encoder's weight-gradient shapes: dense1 / dense2 (bias gradient = column sums of dy:
+    bsum), the packed q / k / v projection (one product, M = 3 F, bias gradient = column sums of the FIRST operand: asum) and
+    the output projection."""
+    D = npm.device
+    k = B * S
+    rng = np.random.default_rng(m * 7 + n)
+    a = rng.standard_normal([k, m], dtype=np.float32)
+    b = rng.standard_normal([k, n], dtype=np.float32) * np.float32(0.01)
+    want = np.zeros([m, n])
+    step = 8192
+    for lo in range(0, k, step):
+        want += a[lo:lo + step].astype(np.float64).T @ b[lo:lo + step].astype(np.float64)
+    src = b if which == 'bsum' else a
+    want_sum = src.astype(np.float64).sum(axis=0)
+    c = D.full([m, n], np.nan)
+    sums = D.full([src.shape[1]], np.nan)
+    D.gemm(m, n, k, D.Mat(D.from_host(a), m), D.Mat(D.from_host(b), n), D.Mat(c, n), trans_a=True, **{which + '_out': sums})
+    assert npm._C.last_math() == exact_modes
+    tol = FULL_K_TOL[exact_modes]
+    got = c.numpy().astype(np.float64)
+    print(f'full-K dw {m}x{n}x{k} {exact_modes}: scaled error {np.abs(got - want).max() / np.abs(want).max():.2e}, '
+          f'{which} {np.abs(sums.numpy() - want_sum).max() / np.abs(want_sum).max():.2e}')
+    assert_close(got, want, tol=tol, what=f'dw {m}x{n}x{k} {exact_modes}')
+    assert_close(sums, want_sum, tol=tol, what=f'{which} {exact_modes}')
+    # the same product again: bitwise reproducible (fixed-order slab reduction, no float atomics)
+    c2 = D.full([m, n], np.nan)
+    D.gemm(m, n, k, D.Mat(D.from_host(a), m), D.Mat(D.from_host(b), n), D.Mat(c2, n), trans_a=True, **{which + '_out': sums})
+    np.testing.assert_array_equal(c2.numpy(), c.numpy())
+
+
+def test_conv_c3_filter_gradient_at_full_size_against_fp64(npm):
+    """C3's dw and db over ALL 256 samples (K = 12.8 M pixels per tap) against the oracle's tap-by-tap products in fp64
+    (oracle conv2d_grad_w = reference conv.py:185-194; nine dgemms per chunk of samples, summed over the chunks).  The ReLU
+    mask comes from the device's own pre-activation (read back), so no branch of activations.py:19 can differ between the
+    two sides.  Exact-f32 MFMA and the split-bf16 mode."""
+    D = npm.device
+    n, hw, c0, c1, k = 256, 224, 64, 128, 3
+    rng = np.random.default_rng(11)
+    layer = npm.layers.Conv2D(channels=c1, kernel_size=k)
+    layer(D.from_host(np.zeros([1, 4, 4, c0], dtype=np.float32)))
+    layer._w.set((np.clip(rng.standard_normal([k, k, c0, c1]), -1, 1) / np.sqrt(k * k * c0)).astype(np.float32))
+    layer._b.set(np.clip(rng.standard_normal([c1]), -1, 1).astype(np.float32))
+    per_x, per_y = hw * hw * c0, hw * hw * c1
+    x_dev, dy_dev = D.empty([n, hw, hw, c0]), D.empty([n, hw, hw, c1])
+    # 16 drawn samples; sample s = one of them, shifted along the width and scaled: all 256 differ, drawn in seconds
+    base_x = rng.standard_normal([16, hw, hw, c0], dtype=np.float32)
+    base_d = rng.standard_normal([16, hw, hw, c1], dtype=np.float32) * np.float32(0.01)
+    for s in range(n):
+        shift, gain = s // 16, np.float32(0.5 + s / n)
+        x_dev.flat_view(s * per_x, [hw, hw, c0]).set(np.roll(base_x[s % 16], shift, axis=1) * gain)
+        dy_dev.flat_view(s * per_y, [hw, hw, c1]).set(np.roll(base_d[s % 16], -shift, axis=0) * gain)
+    del base_x, base_d
+    try:
+        for mode in ('f32', 'bf16x3'):
+            npm.set_math(mode)
+            rec = GradRecorder()
+            layer(x_dev)
+            pre = layer._activation._x
+            layer(dy_dev, backprop=True, optimizer_=rec)
+            got = {key[1]: np.asarray(v).astype(np.float64) for key, v in rec.grads.items()}
+            want_w, want_b = np.zeros([k, k, c0, c1]), np.zeros([c1])
+            chunk = 8
+            for lo in range(0, n, chunk):
+                xs = x_dev.flat_view(lo * per_x, [chunk, hw, hw, c0]).numpy().astype(np.float64)
+                ds = dy_dev.flat_view(lo * per_y, [chunk, hw, hw, c1]).numpy()
+                ps = pre.flat_view(lo * per_y, [chunk, hw, hw, c1]).numpy()
+                g = np.where(ps >= 0, ds, np.float32(0)).astype(np.float64)            # activations.py:19 on the device's own pre
+                want_w += O.conv2d_grad_w(g, xs, k)
+                want_b += g.sum(axis=(0, 1, 2))
+            print(f'C3 full dw {mode}: scaled error {np.abs(got["_w"] - want_w).max() / np.abs(want_w).max():.2e}, '
+                  f'db {np.abs(got["_b"] - want_b).max() / np.abs(want_b).max():.2e}')
+            assert_close(got['_w'], want_w, tol=2e-6, what=f'{mode} dw, all {n} samples')
+            assert_close(got['_b'], want_b, tol=2e-6, what=f'{mode} db, all {n} samples')
+            del pre
+    finally:
+        npm.set_math('f32')

@@ -1,6 +1,7 @@
 """GPU: the parity bound of BASELINE.json ("matching NumPy within 1e-4 rel") as ASSERTIONS, once per BASELINE config
 at full width (C1 and C2 whole; C3, C4, C5 on two samples of the full-shape problem -- every op is per sample), in the
-headline arithmetic (exact-f32 MFMA), against the NumPy oracle run in fp64 on the same inputs.
+headline arithmetic (exact-f32 MFMA) AND in every other arithmetic bench.py reports a throughput line for (bf16x3, f16x2),
+each against its own bound from include/npm_hip.h (NPM_PARITY_*), against the NumPy oracle run in fp64 on the same inputs.
 
 How "1e-4 rel" is read: fp32 contractions reorder sums, so an element's error scales with the
 magnitude of the TENSOR (the terms that cancelled in it), not of the element; a purely relative bound on an element
@@ -20,14 +21,34 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_baseline_configs_meet_the_stated_bound():
+def _reported_modes():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench.reported_math_modes()
+
+
+def test_every_reported_mode_has_a_bound():
+    """bench.py's lines: the headline (f32) and one per alternative arithmetic -- exactly the modes include/npm_hip.h gives a
+    parity bound, so none is reported untested."""
+    from np_modeling_amd import _C
+    assert _reported_modes() == ['f32', 'bf16x3', 'f16x2']
+    assert set(_reported_modes()) == set(_C.parity_bounds())
+    assert all(0 < scaled <= rel <= 1e-4 for rel, scaled in _C.parity_bounds().values())      # none looser than north_star's
+
+
+@pytest.mark.parametrize('mode', ['f32', 'bf16x3', 'f16x2'])
+def test_baseline_configs_meet_the_stated_bound(mode):
+    from np_modeling_amd import _C
     sys.path.insert(0, os.path.join(ROOT, 'tools'))
     import parity_report
+    assert mode in _reported_modes()
+    rel_bound, scaled_bound = _C.parity_bounds()[mode]
     parity_report.ROWS.clear()
-    parity_report.main(modes=('f32',))
+    parity_report.main(modes=(mode,))
     rows = list(parity_report.ROWS)
+    assert {r[1] for r in rows} == {mode}
     configs = {r[0].split()[0] for r in rows}
     assert configs == {'C1', 'C2', 'C3', 'C4', 'C5'}, configs            # every BASELINE config took part
     assert len(rows) >= 12            # (dw / db of the Dense configs join when no ReLU decision is ambiguous)
-    bad = [r for r in rows if not (r[3] <= parity_report.REL_BOUND and r[5] <= parity_report.SCALED_BOUND)]
+    bad = [r for r in rows if not (r[3] <= rel_bound and r[5] <= scaled_bound)]
     assert not bad, '\n'.join(f'{c} {n}: rel {a:.2e} scaled {s:.2e}' for c, _, n, a, _, s in bad)

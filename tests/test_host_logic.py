@@ -718,6 +718,45 @@ def test_explicit_rendezvous_file_shared_by_ranks_of_different_parents(tmp_path)
     assert all('NPM_LAUNCH_TOKEN' in o for o in outs), outs
 
 
+def test_explicit_file_without_token_or_sibling_proof_fails_at_once(tmp_path, monkeypatch):
+    """An explicit NPM_RENDEZVOUS_FILE, no token, no job id and NO LOCAL_WORLD_SIZE (ranks started from separate shells, or
+    on several nodes by a launcher that does not export it): the parent-pid token would differ per rank and every rank but 0
+    would poll for 300 s.  The error comes at once; with LOCAL_WORLD_SIZE == WORLD_SIZE (siblings) the parent token is fine."""
+    from np_modeling_amd import _C, parallel
+    for var in ('NPM_LAUNCH_TOKEN', 'TORCHELASTIC_RUN_ID', 'SLURM_JOB_ID', 'LOCAL_WORLD_SIZE'):
+        monkeypatch.delenv(var, raising=False)
+    monkeypatch.setenv('NPM_RENDEZVOUS_FILE', str(tmp_path / 'id'))
+    monkeypatch.setenv('WORLD_SIZE', '2')
+    with pytest.raises(_C.NpmError, match='NPM_LAUNCH_TOKEN'):
+        parallel._launch_token()
+    monkeypatch.setenv('LOCAL_WORLD_SIZE', '2')
+    assert parallel._launch_token().startswith(f'{os.getppid()}-')
+    monkeypatch.setenv('WORLD_SIZE', '1')                      # a single rank needs no proof
+    monkeypatch.delenv('LOCAL_WORLD_SIZE')
+    assert parallel._launch_token().startswith(f'{os.getppid()}-')
+
+
+def test_ipc_mode_is_set_for_externally_launched_ranks():
+    """HSA_ENABLE_IPC_MODE_LEGACY=0 (dmabuf IPC: what this pool's driver supports) must be in the environment before the
+    runtime initialises whenever the process is one of several ranks -- also under an external launcher, not only under
+    np_modeling_amd/launch.py.  A value the user chose is kept; a single process is left alone."""
+    from np_modeling_amd import _C, launch
+    env = {'WORLD_SIZE': '8'}
+    assert _C.ipc_env_for_multi_rank(env) is True and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    env = {'WORLD_SIZE': '2', 'HSA_ENABLE_IPC_MODE_LEGACY': '1'}
+    assert _C.ipc_env_for_multi_rank(env) is True and env['HSA_ENABLE_IPC_MODE_LEGACY'] == '1'
+    for env in ({}, {'WORLD_SIZE': '1'}, {'WORLD_SIZE': ''}):
+        assert _C.ipc_env_for_multi_rank(env) is False and 'HSA_ENABLE_IPC_MODE_LEGACY' not in env
+    assert launch.rank_environment(0, 2, '/tmp/x', base={})['HSA_ENABLE_IPC_MODE_LEGACY'] == '0'
+    # parallel.init() and _C.lib() call it before the device library is loaded / initialised
+    import inspect
+    from np_modeling_amd import parallel
+    src = inspect.getsource(parallel.init)
+    assert src.index('ipc_env_for_multi_rank') < src.index('_C.lib()')
+    src = inspect.getsource(_C.lib)
+    assert src.index('ipc_env_for_multi_rank') < src.index('load_library') < src.index('npm_init')
+
+
 def test_stale_rendezvous_file_with_the_same_address_is_rejected(tmp_path, monkeypatch):
     """A crashed job leaves its file at a reused NPM_RENDEZVOUS_FILE; the next job has the SAME MASTER_ADDR / MASTER_PORT.  Its
     ranks must skip that file whichever way they were launched: self-launched ranks carry a fresh random token per launch,
@@ -855,6 +894,71 @@ def test_one_optimizer_launch_per_encoder_backward(npm, monkeypatch, kind, norm_
     assert len(got) == len(want) == 16
     for a, b in zip(got, want):
         np.testing.assert_array_equal(a, b)
+
+
+def test_queued_updates_keep_program_order(npm, monkeypatch):
+    """Any ``Optimizer`` subclass may run inside a backward's ``coalesced_updates()``: only ``+=`` / ``-=`` are queued (and
+    launched sorted by address), so everything else must see them in program order.  Weight decay after the step
+    (``var -= lr * g; var *= 1 - wd``), a momentum buffer that is updated and then applied (write -> read of one array in two
+    queued updates), two updates of one variable, and a host read in between -- each equal to the unqueued run."""
+    D = npm.device
+    monkeypatch.setattr(D, 'COALESCE_UPDATES', True)
+
+    def decay(var, g, vel):
+        var -= 0.5 * g
+        var *= 0.5                      # not queued: must come AFTER the queued step
+        return var
+
+    def momentum(var, g, vel):
+        vel *= 0.9
+        vel += g                        # queued, writes vel
+        var -= 0.1 * vel                # queued, READS vel: must see the line above applied
+        return var
+
+    def twice(var, g, vel):
+        var -= 0.5 * g
+        var += 0.25 * var.copy()        # copy() reads var between two queued updates of it
+        return var
+
+    def peek(var, g, vel):
+        var -= 0.5 * g
+        seen.append(np.asarray(var).copy())
+        var -= 0.5 * g
+        return var
+
+    for rule in (decay, momentum, twice, peek):
+        results = []
+        for queued in (False, True):
+            seen = []
+            block = D.from_host(np.arange(24, dtype=np.float32))              # neighbours in one block, like an arena
+            var, vel = block.flat_view(8, [8]), block.flat_view(0, [8])
+            g = D.from_host(np.linspace(-1, 1, 8).astype(np.float32))
+            if queued:
+                with D.coalesced_updates() as queue:
+                    rule(var, g, vel)
+                assert queue.drains >= 1, rule.__name__
+                assert npm._C._ORDER_HOOK is None
+            else:
+                rule(var, g, vel)
+            results.append((block.numpy().copy(), [s.copy() for s in seen]))
+        np.testing.assert_array_equal(results[0][0], results[1][0], err_msg=rule.__name__)
+        for a, b in zip(results[0][1], results[1][1]):
+            np.testing.assert_array_equal(a, b, err_msg=rule.__name__)
+    # the advisor's reproduction: 0.1 when called directly
+    var, g = D.from_host(np.float32([1.0])), D.from_host(np.float32([8.0]))
+    with D.coalesced_updates():
+        var -= 0.1 * g
+        var *= 0.5
+    np.testing.assert_allclose(var.numpy(), [0.1], rtol=1e-6)
+    # updates of disjoint arrays still wait together and run joined
+    block = D.from_host(np.zeros(16, dtype=np.float32))
+    grads = D.from_host(np.ones(16, dtype=np.float32))
+    with D.coalesced_updates() as queue:
+        for at in (8, 0, 12, 4):
+            v = block.flat_view(at, [4])
+            v -= 1.0 * grads.flat_view(at, [4])
+    assert queue.launches == 1 and queue.drains == 0 and queue.updates == 4
+    np.testing.assert_array_equal(block.numpy(), -np.ones(16, dtype=np.float32))
 
 
 def test_rebound_parameter_leaves_the_arena(npm, monkeypatch):
