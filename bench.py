@@ -449,7 +449,7 @@ def main():
         # two more lines beside the BASELINE configs (no CPU baseline; not BASELINE.json's): C4 under a causal mask -- the mask's tile
         # summary lets the fused kernels skip empty tiles -- and C4's dimensions with 16 heads of 64 (the 8-wave backward at head size 64)
         result['configs_extra'] = {}
-        for name in ('C4M', 'C4D64'):
+        for name in ('C4M', 'C4D64', 'C5D'):     # C5D: the headline workload with drop_rate 0.1 (dropout inside the LayerNorm kernels)
             result['configs_extra'][name] = config_bench.run_config(name, npm, D, min_seconds=args.configs_min_seconds)
             D.trim_pool()
     if comm.active:

@@ -227,6 +227,18 @@ int npm_layernorm_fwd(const float *x, const float *gamma, const float *beta, flo
 int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const float *rstd,
                       const float *gamma, const float *residual, int64_t rows, int64_t d,
                       float *dx, float *dgamma, float *dbeta);
+/* LayerNormalization of DropOut's output without ever storing it -- in the reference's encoder / decoder a DropOut always sits
+ * directly in front of a LayerNormalization (transformer.py:35-36,40-41,49-50,55-56):
+ *   forward   xd = mask ? x / keep_prob : 0 (normalizations.py:21-23) on the way in, then npm_layernorm_fwd's arithmetic on xd;
+ *   backward  the same xd again from x and mask, npm_layernorm_bwd's arithmetic, then DropOut.backward on the way out
+ *             (normalizations.py:27-30): dx = mask ? dxd / keep_prob : 0 [+ residual].
+ * mask: one byte per element (0 = dropped), 4-byte aligned.  Bit-equal to npm_mask_scale + npm_layernorm_fwd / npm_layernorm_bwd +
+ * npm_mask_scale (+ npm_add).  Rows with d % 4 != 0 or d > 4096 are NPM_E_UNSUPPORTED: compose the calls above. */
+int npm_layernorm_dropout_fwd(const float *x, const unsigned char *mask, float keep_prob, const float *gamma, const float *beta,
+                              float eps, int64_t rows, int64_t d, float *z, float *mean, float *rstd);
+int npm_layernorm_dropout_bwd(const float *dz, const float *x, const unsigned char *mask, float keep_prob, const float *mean,
+                              const float *rstd, const float *gamma, const float *residual, int64_t rows, int64_t d,
+                              float *dx, float *dgamma, float *dbeta);
 
 /* ---- Conv2D: NHWC x HWIO, SAME, stride 1, odd k (layers/conv.py:74-194) ----
  * Implicit-im2col GEMM on the fp32 MFMA; the im2col matrix is never materialised. */
@@ -339,7 +351,8 @@ int npm_mask_scale(const float *x, const unsigned char *mask, float *y, size_t n
 /* The same with the mask drawn ON THE DEVICE: element i keeps its value when word (i & 3) of
  * Philox4x32-10(counter = (i / 4, offset), key = seed) is below keep_prob * 2^32; the byte mask is written too (the layer's
  * `_mask` stays readable).  Deterministic in (seed, offset); not the host generator's stream -- seeded parity with the
- * reference needs the host-drawn path above. */
+ * reference needs the host-drawn path above.  x == y == NULL: only the mask is drawn (its consumer applies it:
+ * npm_layernorm_dropout_fwd / _bwd). */
 int npm_dropout_philox(const float *x, float *y, unsigned char *mask, size_t n, float keep_prob, uint64_t seed, uint64_t offset);
 
 #ifdef __cplusplus

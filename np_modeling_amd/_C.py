@@ -128,6 +128,8 @@ SIGNATURES = {
     'npm_softmax_bwd': [_P, _P, _P, _I64, _I64, _F],
     'npm_layernorm_fwd': [_P, _P, _P, _F, _I64, _I64, _P, _P, _P],
     'npm_layernorm_bwd': [_P, _P, _P, _P, _P, _P, _I64, _I64, _P, _P, _P],
+    'npm_layernorm_dropout_fwd': [_P, _P, _F, _P, _P, _F, _I64, _I64, _P, _P, _P],
+    'npm_layernorm_dropout_bwd': [_P, _P, _P, _F, _P, _P, _P, _P, _I64, _I64, _P, _P, _P],
     'npm_conv2d_fwd': [C.POINTER(npm_conv2d)],
     'npm_conv2d_bwd_x': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],
     'npm_conv2d_bwd_w': [_P, _P, _P, _I32, _I32, _I32, _I32, _I32, _I32],

@@ -47,22 +47,29 @@ __device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, uns
 // key = seed); keep when word < threshold; y = keep ? x / keep_prob : 0, mask = keep as a byte.
 __global__ void __launch_bounds__(256)
 dropout_philox_kernel(const float *__restrict__ x, float *__restrict__ y, unsigned char *__restrict__ mask, size_t n,
-                      float inv_keep, unsigned long long threshold, unsigned k0, unsigned k1, unsigned long long offset) {
+                      float keep_prob, unsigned long long threshold, unsigned k0, unsigned k1, unsigned long long offset) {
     const size_t groups = (n + 3) / 4;
     for (size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x; g < groups; g += (size_t)gridDim.x * blockDim.x) {
         unsigned c[4] = {(unsigned)g, (unsigned)(g >> 32), (unsigned)offset, (unsigned)(offset >> 32)};
         philox4x32_10(c, k0, k1);
         const size_t i = 4 * g;
-        if (i + 3 < n && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0) {
+        if (y == nullptr) {                  // the mask alone (its consumer applies it: npm_layernorm_dropout_fwd / _bwd)
+            if (i + 3 < n && (((uintptr_t)mask) & 3) == 0) {
+                *reinterpret_cast<unsigned *>(mask + i) = (unsigned)(c[0] < threshold) | ((unsigned)(c[1] < threshold) << 8) |
+                                                          ((unsigned)(c[2] < threshold) << 16) | ((unsigned)(c[3] < threshold) << 24);
+            } else {
+                for (int e = 0; e < 4 && i + e < n; ++e) mask[i + e] = c[e] < threshold;
+            }
+        } else if (i + 3 < n && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && (((uintptr_t)mask) & 3) == 0) {
             const float4 v = *reinterpret_cast<const float4 *>(x + i);
             const bool b0 = c[0] < threshold, b1 = c[1] < threshold, b2 = c[2] < threshold, b3 = c[3] < threshold;
-            *reinterpret_cast<float4 *>(y + i) = make_float4(b0 ? v.x * inv_keep : 0.f, b1 ? v.y * inv_keep : 0.f,
-                                                              b2 ? v.z * inv_keep : 0.f, b3 ? v.w * inv_keep : 0.f);
+            *reinterpret_cast<float4 *>(y + i) = make_float4(b0 ? v.x / keep_prob : 0.f, b1 ? v.y / keep_prob : 0.f,
+                                                              b2 ? v.z / keep_prob : 0.f, b3 ? v.w / keep_prob : 0.f);
             *reinterpret_cast<unsigned *>(mask + i) = (unsigned)b0 | ((unsigned)b1 << 8) | ((unsigned)b2 << 16) | ((unsigned)b3 << 24);
         } else {
             for (int e = 0; e < 4 && i + e < n; ++e) {
                 const bool keep = c[e] < threshold;
-                y[i + e] = keep ? x[i + e] * inv_keep : 0.f;
+                y[i + e] = keep ? x[i + e] / keep_prob : 0.f;
                 mask[i + e] = keep;
             }
         }
@@ -201,13 +208,13 @@ int npm_xent_bwd(const float *y, const float *targets, float *dy, size_t n) {
 int npm_dropout_philox(const float *x, float *y, unsigned char *mask, size_t n, float keep_prob, uint64_t seed, uint64_t offset) {
     NPM_REQUIRE_INIT();
     if (n == 0) return NPM_OK;
-    NPM_ARG(x && y && mask && keep_prob > 0.f && keep_prob <= 1.f);
+    NPM_ARG(mask && ((x && y) || (!x && !y)) && keep_prob > 0.f && keep_prob <= 1.f);      // x = y = NULL: draw the mask only
     const size_t groups = (n + 3) / 4;
     // keep an element when its 32 random bits are below keep_prob * 2^32 (integer compare: reproducible anywhere)
     const double scaled = (double)keep_prob * 4294967296.0;
     const uint64_t threshold = scaled >= 4294967296.0 ? 4294967296ull : (uint64_t)scaled;
     hipLaunchKernelGGL(dropout_philox_kernel, dim3(grid_for(groups, 1 << 20)), dim3(256), 0, npm::ctx().stream, x, y, mask, n,
-                       1.f / keep_prob, threshold, (unsigned)seed, (unsigned)(seed >> 32), offset);
+                       keep_prob, threshold, (unsigned)seed, (unsigned)(seed >> 32), offset);
     NPM_CHECK_LAUNCH();
     return NPM_OK;
 }

@@ -520,17 +520,33 @@ attn_rowdot_kernel(const float *__restrict__ a, const float *__restrict__ b, flo
 }
 
 // ---- LayerNorm ---------------------------------------------------------------------
-template <int VPL, bool NT, bool NTS = NT>
+// DROP: the row is DropOut's output, formed on the way in (reference transformer.py:35-36,40-41,49-50,55-56: a dropout
+// always sits directly in front of a LayerNormalization): x_i <- mask_i ? x_i / keep : 0 (normalizations.py:21-23), one byte
+// of mask per element, four per 32-bit load.  The dropped tensor is never written.
+__device__ __forceinline__ float4 drop4(float4 v, unsigned m, float keep) {
+    return make_float4((m & 0xffu) ? v.x / keep : 0.f, (m & 0xff00u) ? v.y / keep : 0.f,
+                       (m & 0xff0000u) ? v.z / keep : 0.f, (m & 0xff000000u) ? v.w / keep : 0.f);
+}
+
+template <int VPL, bool NT, bool NTS = NT, bool DROP = false>
 __global__ void __launch_bounds__(256)
 layernorm_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gamma, const float *__restrict__ beta,
                      float eps, long rows, int d, float *__restrict__ z, float *__restrict__ mean_out,
-                     float *__restrict__ rstd_out) {
+                     float *__restrict__ rstd_out, const unsigned char *__restrict__ mask = nullptr, float keep = 1.f) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * ROWS_PER_BLOCK + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int nvec = d >> 2;
     float4 v[VPL];
     load_row<VPL, NT>(x + row * d, nvec, lane, v, 0.f);
+    if (DROP) {
+        const unsigned *mrow = reinterpret_cast<const unsigned *>(mask + row * d);
+#pragma unroll
+        for (int j = 0; j < VPL; ++j) {
+            const int c = lane + WAVE * j;
+            if (c < nvec) v[j] = drop4(v[j], mrow[c], keep);
+        }
+    }
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < VPL; ++j) s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
@@ -583,12 +599,14 @@ layernorm_fwd_generic(const float *__restrict__ x, const float *__restrict__ gam
 // Backward: each wave walks rows (grid-stride) and keeps its dgamma/dbeta partials for the
 // columns it owns in registers; every wave writes one partial row and a column sum over
 // the wave partials (fixed order, reproducible) finishes the job.
-template <int VPL, bool NT, bool NTS = NT>
+// DROP: x is the input of the DropOut in front of this LayerNorm: the row is dropped again on the way in (as the forward
+// did) and the input gradient goes through DropOut.backward (normalizations.py:27-30) on the way out, before the residual.
+template <int VPL, bool NT, bool NTS = NT, bool DROP = false>
 __global__ void __launch_bounds__(256)
 layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, const float *__restrict__ mean,
                      const float *__restrict__ rstd, const float *__restrict__ gamma,
                      const float *__restrict__ residual, long rows, int d, float *__restrict__ dx,
-                     float *__restrict__ part) {
+                     float *__restrict__ part, const unsigned char *__restrict__ mask = nullptr, float keep = 1.f) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nvec = d >> 2;
     float4 gm[VPL], dg[VPL], db[VPL];
@@ -608,6 +626,16 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
         load_row<VPL, NT>(dz + row * d, nvec, lane, g, 0.f);
         load_row<VPL, NT>(x + row * d, nvec, lane, yh, 0.f);
         if (residual) load_row<VPL, NT>(residual + row * d, nvec, lane, res, 0.f);
+        unsigned mk[VPL];
+        if (DROP) {
+            const unsigned *mrow = reinterpret_cast<const unsigned *>(mask + row * d);
+#pragma unroll
+            for (int j = 0; j < VPL; ++j) {
+                const int c = lane + WAVE * j;
+                mk[j] = c < nvec ? mrow[c] : 0u;
+                yh[j] = drop4(yh[j], mk[j], keep);
+            }
+        }
         const float mu = mean[row], rs = rstd[row];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -630,6 +658,7 @@ layernorm_bwd_kernel(const float *__restrict__ dz, const float *__restrict__ x, 
             o.x = rs * (g[j].x - m1 - yh[j].x * m2); o.y = rs * (g[j].y - m1 - yh[j].y * m2);
             o.z = rs * (g[j].z - m1 - yh[j].z * m2); o.w = rs * (g[j].w - m1 - yh[j].w * m2);
             if (c < nvec) {
+                if (DROP) o = drop4(o, mk[j], keep);
                 if (residual) { o.x += res[j].x; o.y += res[j].y; o.z += res[j].z; o.w += res[j].w; }
                 stg4<NTS>(dx + row * d + 4 * c, o);
             }
@@ -827,6 +856,71 @@ int npm_softmax_bwd(const float *y, const float *dy, float *dx, int64_t rows, in
     }
     NPM_CHECK_LAUNCH();
     return NPM_OK;
+}
+
+#define NPM_ROW_DISPATCH_DROP(KERNEL, NT, n, ...)                                                                    \
+    do {                                                                                                            \
+        if (n <= 256) hipLaunchKernelGGL((KERNEL<1, NT, NT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);       \
+        else if (n <= 512) hipLaunchKernelGGL((KERNEL<2, NT, NT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);  \
+        else if (n <= 1024) hipLaunchKernelGGL((KERNEL<4, NT, NT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else if (n <= 2048) hipLaunchKernelGGL((KERNEL<8, NT, NT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__); \
+        else hipLaunchKernelGGL((KERNEL<16, NT, NT, true>), dim3(grid), dim3(256), 0, s, __VA_ARGS__);               \
+    } while (0)
+
+// The row-in-registers kernels with a dropout mask in front (npm_layernorm_dropout_fwd / _bwd): same hint placement as the
+// plain kernels at d in (512, 1024] (NPM_TUNE_LN_NT_SPLIT mode 1: loads only), the default elsewhere.
+static bool ln_dropout_ok(int64_t d, const void *mask) { return d % 4 == 0 && d <= 4096 && ((uintptr_t)mask & 3) == 0; }
+
+int npm_layernorm_dropout_fwd(const float *x, const unsigned char *mask, float keep_prob, const float *gamma, const float *beta,
+                              float eps, int64_t rows, int64_t d, float *z, float *mean, float *rstd) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && d >= 1 && keep_prob > 0.f);
+    if (rows == 0) return NPM_OK;
+    NPM_ARG(x && mask && gamma && beta && z && mean && rstd);
+    NPM_ARG((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK < (1L << 31));
+    if (!(ln_dropout_ok(d, mask) && aligned16(x) && aligned16(z) && aligned16(gamma) && aligned16(beta)))
+        return npm::fail(NPM_E_UNSUPPORTED, "npm_layernorm_dropout_fwd: d %% 4 == 0, d <= 4096 and 16-byte aligned rows (npm_mask_scale + npm_layernorm_fwd otherwise)");
+    hipStream_t s = npm::ctx().stream;
+    const int grid = (int)((rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK);
+    const bool nt = stream_nt(sizeof(float) * (size_t)rows * (size_t)d);
+    if (nt && (g_ln_nt_split >> 2) == 1 && d > 512 && d <= 1024)
+        hipLaunchKernelGGL((layernorm_fwd_kernel<4, true, false, true>), dim3(grid), dim3(256), 0, s, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd, mask, keep_prob);
+    else if (nt) NPM_ROW_DISPATCH_DROP(layernorm_fwd_kernel, true, d, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd, mask, keep_prob);
+    else NPM_ROW_DISPATCH_DROP(layernorm_fwd_kernel, false, d, x, gamma, beta, eps, (long)rows, (int)d, z, mean, rstd, mask, keep_prob);
+    NPM_CHECK_LAUNCH();
+    return NPM_OK;
+}
+
+int npm_layernorm_dropout_bwd(const float *dz, const float *x, const unsigned char *mask, float keep_prob, const float *mean,
+                              const float *rstd, const float *gamma, const float *residual, int64_t rows, int64_t d,
+                              float *dx, float *dgamma, float *dbeta) {
+    NPM_REQUIRE_INIT();
+    NPM_ARG(rows >= 0 && d >= 1 && keep_prob > 0.f);
+    NPM_ARG(dgamma != nullptr && dbeta != nullptr);
+    if (rows == 0) {
+        int rc = npm_fill_f32(dgamma, 0.f, (size_t)d);
+        return rc ? rc : npm_fill_f32(dbeta, 0.f, (size_t)d);
+    }
+    NPM_ARG(dz && x && mask && mean && rstd && gamma && dx);
+    if (!(ln_dropout_ok(d, mask) && aligned16(dz) && aligned16(x) && aligned16(dx) && aligned16(gamma) && (residual == nullptr || aligned16(residual))))
+        return npm::fail(NPM_E_UNSUPPORTED, "npm_layernorm_dropout_bwd: d %% 4 == 0, d <= 4096 and 16-byte aligned rows");
+    hipStream_t s = npm::ctx().stream;
+    const bool nt = stream_nt(sizeof(float) * (size_t)rows * (size_t)d);
+    const long row_blocks = (rows + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK;
+    const int grid = (int)std::min<long>(row_blocks, (long)g_ln_bwd_blocks_per_cu * npm::ctx().num_cus);
+    npm::Scratch part;
+    int rc = part.alloc(sizeof(float) * 2 * (size_t)grid * d);
+    if (rc) return rc;
+    float *pp = (float *)part.ptr;
+    if (nt && (g_ln_nt_split & 3) == 1 && d > 512 && d <= 1024)
+        hipLaunchKernelGGL((layernorm_bwd_kernel<4, true, false, true>), dim3(grid), dim3(256), 0, s, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp, mask, keep_prob);
+    else if (nt) NPM_ROW_DISPATCH_DROP(layernorm_bwd_kernel, true, d, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp, mask, keep_prob);
+    else NPM_ROW_DISPATCH_DROP(layernorm_bwd_kernel, false, d, dz, x, mean, rstd, gamma, residual, (long)rows, (int)d, dx, pp, mask, keep_prob);
+    NPM_CHECK_LAUNCH();
+    if (dbeta == dgamma + d) return colsum_impl(pp, dgamma, grid, 2 * d, 2 * d);
+    rc = colsum_impl(pp, dgamma, grid, d, 2 * d);
+    if (rc) return rc;
+    return colsum_impl(pp + d, dbeta, grid, d, 2 * d);
 }
 
 int npm_layernorm_fwd(const float *x, const float *gamma, const float *beta, float eps,

@@ -846,12 +846,23 @@ def attn_rowdot(a: DeviceArray, b: DeviceArray) -> DeviceArray:
     return out
 
 
-def layernorm_fwd(x: DeviceArray, gamma: DeviceArray, beta: DeviceArray, eps: float):
-    """Returns (z, mean, rstd); mean/rstd have x's shape with the last axis reduced to 1."""
+def layernorm_dropout_supported(d: int) -> bool:
+    """Row lengths npm_layernorm_dropout_fwd / _bwd take (include/npm_hip.h): the row-in-registers kernels."""
+    return d % 4 == 0 and d <= 4096
+
+
+def layernorm_fwd(x: DeviceArray, gamma: DeviceArray, beta: DeviceArray, eps: float, drop=None):
+    """Returns (z, mean, rstd); mean/rstd have x's shape with the last axis reduced to 1.  ``drop = (mask bytes, keep_prob)``:
+    the row is DropOut's output, formed on the way in (the dropped tensor is never stored)."""
     d = x.shape[-1]
     rows = x.size // d
     stat_shape = tuple(x.shape[:-1]) + (1,)
     z, mean, rstd = empty(x.shape), empty(stat_shape), empty(stat_shape)
+    if drop is not None:
+        with _timed('layernorm_fwd', nbytes=9.0 * x.size + 8.0 * rows):
+            _C.check(_C.lib().npm_layernorm_dropout_fwd(x.ptr, drop[0].ptr, float(drop[1]), gamma.ptr, beta.ptr, float(eps), rows, d,
+                                                        z.ptr, mean.ptr, rstd.ptr), 'npm_layernorm_dropout_fwd')
+        return z, mean, rstd
     with _timed('layernorm_fwd', nbytes=8.0 * x.size + 8.0 * rows):
         _C.check(_C.lib().npm_layernorm_fwd(x.ptr, gamma.ptr, beta.ptr, float(eps), rows, d,
                                             z.ptr, mean.ptr, rstd.ptr), 'npm_layernorm_fwd')
@@ -859,13 +870,20 @@ def layernorm_fwd(x: DeviceArray, gamma: DeviceArray, beta: DeviceArray, eps: fl
 
 
 def layernorm_bwd(dz: DeviceArray, x: DeviceArray, mean: DeviceArray, rstd: DeviceArray, gamma: DeviceArray,
-                  dgamma: DeviceArray, dbeta: DeviceArray, residual: Optional[DeviceArray] = None) -> DeviceArray:
+                  dgamma: DeviceArray, dbeta: DeviceArray, residual: Optional[DeviceArray] = None, drop=None) -> DeviceArray:
+    """``drop = (mask bytes, keep_prob)``: ``x`` is the input of the DropOut in front of the norm; the result is the gradient
+    with respect to THAT (DropOut.backward applied on the way out, before the residual)."""
     d = x.shape[-1]
     rows = x.size // d
     dx = empty(dz.shape)
+    res = None if residual is None else residual.ptr
+    if drop is not None:
+        with _timed('layernorm_bwd', nbytes=(17.0 if residual is not None else 13.0) * x.size + 8.0 * rows):
+            _C.check(_C.lib().npm_layernorm_dropout_bwd(dz.ptr, x.ptr, drop[0].ptr, float(drop[1]), mean.ptr, rstd.ptr, gamma.ptr,
+                                                        res, rows, d, dx.ptr, dgamma.ptr, dbeta.ptr), 'npm_layernorm_dropout_bwd')
+        return dx
     with _timed('layernorm_bwd', nbytes=(16.0 if residual is not None else 12.0) * x.size + 8.0 * rows):
-        _C.check(_C.lib().npm_layernorm_bwd(dz.ptr, x.ptr, mean.ptr, rstd.ptr, gamma.ptr,
-                                            None if residual is None else residual.ptr, rows, d,
+        _C.check(_C.lib().npm_layernorm_bwd(dz.ptr, x.ptr, mean.ptr, rstd.ptr, gamma.ptr, res, rows, d,
                                             dx.ptr, dgamma.ptr, dbeta.ptr), 'npm_layernorm_bwd')
     return dx
 

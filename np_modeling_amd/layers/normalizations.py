@@ -83,6 +83,25 @@ class DropOut(layer.Layer):
             return self._apply(x)
         return x
 
+    def _draw(self, shape):
+        """The mask of a forward over a tensor of ``shape`` WITHOUT applying it -- for a consumer that applies it on its way in
+        (LayerNormalization._forward_impl: the encoder's fused path).  Same draws as ``forward``: the host generator's
+        ``np.random.binomial`` call of the reference, or the next Philox offset.  Returns ``(mask bytes, keep_prob)``, or None
+        when this dropout is the identity."""
+        if self._drop_prob == 0.0:
+            return None
+        keep = 1 - self._drop_prob
+        size = D._prod(shape)
+        if _DeviceRng.enabled:
+            self._mask_dev, self._mask_shape, self._host_mask = D.ByteBuffer(size), tuple(shape), None
+            _C.check(_C.lib().npm_dropout_philox(None, None, self._mask_dev.ptr, size, float(keep),
+                                                 _DeviceRng.seed, _DeviceRng.offset), 'npm_dropout_philox')
+            _DeviceRng.offset += 1
+        else:
+            self._mask = np.random.binomial(n=1, p=keep, size=size).reshape(shape)
+            self._mask_dev = D.bytes_from_host(self._mask.astype(np.uint8))
+        return self._mask_dev, keep
+
     def backward(self, dl_dy, *args, **kwargs):
         if self._drop_prob != 0.0:
             return self._apply(dl_dy)
@@ -95,6 +114,8 @@ class LayerNormalization(layer.StatefulLayer):
     gamma first (normalizations.py:40-41).  One wavefront per row; the backward is the closed
     form of the reference's [rows, d, d] Jacobian einsum (normalizations.py:58-71)."""
 
+    _drop = None            # (mask bytes, keep_prob) of the DropOut folded into the last forward, or None
+
     def __init__(self, epsilon: float = 1e-3, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._epsilon = epsilon
@@ -106,12 +127,24 @@ class LayerNormalization(layer.StatefulLayer):
         self._pack_parameters([[(self, '_gamma')], [(self, '_beta')]])
 
     def forward(self, x):
+        return self._forward_impl(x)
+
+    def _forward_impl(self, x, dropout: Optional[DropOut] = None):
+        """``dropout``: the DropOut layer that sits directly in front of this norm in a composite (transformer.py:35-36,
+        40-41,49-50,55-56).  Its mask is drawn here and applied INSIDE the kernels -- forward on the way in, backward on the
+        way in (to rebuild the norm's input) and on the way out (DropOut.backward) -- so ``x`` stays the dropout's input and
+        the dropped tensor is never stored; ``_backward_impl`` then returns the gradient with respect to that input."""
         x = D.as_device(x)
+        drop = dropout._draw(x.shape) if dropout is not None else None      # the dropout runs first: its draws precede this
+        if not self._initialized:                                            # layer's lazy parameter draws (layer.py:33-35)
+            self.initialize(x)
+            self._initialized = True
         gamma, beta = self._param('_gamma'), self._param('_beta')
         d = x.shape[-1]
         assert gamma.shape == (d,), f'{gamma.shape} vs {d}'
         self._x = x
-        z, self._mean, self._rstd = D.layernorm_fwd(x, gamma, beta, self._epsilon)
+        self._drop = drop
+        z, self._mean, self._rstd = D.layernorm_fwd(x, gamma, beta, self._epsilon, drop=self._drop)
         return z
 
     def backward(self, dl_dz, optimizer_):
@@ -126,7 +159,7 @@ class LayerNormalization(layer.StatefulLayer):
         d = x.shape[-1]
         assert dz.size == x.size, f'{dz.shape} vs {x.shape}'
         dgamma, dbeta = scope.take([d], owner=(self, '_gamma')), scope.take([d], owner=(self, '_beta'))
-        dx = D.layernorm_bwd(dz, x, self._mean, self._rstd, gamma, dgamma, dbeta, residual=residual)
+        dx = D.layernorm_bwd(dz, x, self._mean, self._rstd, gamma, dgamma, dbeta, residual=residual, drop=self._drop)
         scope.defer(optimizer_, self, '_gamma', dgamma)
         scope.defer(optimizer_, self, '_beta', dbeta)
         return dx

@@ -1,7 +1,8 @@
 """TransformerEncoder / TransformerDecoder (reference layers/transformer.py:8-203).
 
-Composition only: the sub-layers do the arithmetic.  With ``drop_rate == 0`` (the only
-configuration the reference's tests and the benchmark use) the residual additions of
+Composition only: the sub-layers do the arithmetic.  In the encoder -- with or without dropout: a DropOut always sits
+directly in front of a LayerNormalization there and rides inside that norm's kernels (normalizations.py
+``LayerNormalization._forward_impl``) -- and in the decoder with ``drop_rate == 0`` the residual additions of
 transformer.py:39,53,78,90 (encoder; 130,141,152,170-198 decoder) and the three-way sum of transformer.py:85 are folded into GEMM
 epilogues / the LayerNorm backward kernel, and the ReLU backward of ``dense1`` is folded
 into the epilogue of ``dense2``'s dx GEMM, so no standalone elementwise pass runs.
@@ -19,6 +20,12 @@ from np_modeling_amd.layers import attentions, layer, mlp, normalizations
 
 def _identity_dropout(*dropouts) -> bool:
     return all(d._drop_prob == 0.0 for d in dropouts)
+
+
+def _dropout_folds(features: int, *dropouts) -> bool:
+    """Whether the dropouts can ride inside the LayerNorm kernels behind them (device.layernorm_dropout_supported): always
+    when they are the identity."""
+    return _identity_dropout(*dropouts) or D.layernorm_dropout_supported(features)
 
 
 def _linear_segments(lin):
@@ -69,6 +76,7 @@ class TransformerEncoder(layer.Layer):
         self._norm_first = norm_first
         self._dropout1 = normalizations.DropOut(drop_rate)
         self._dropout2 = normalizations.DropOut(drop_rate)
+        self._fused = True      # which composition the last forward ran (the backward mirrors it)
 
     def initialize(self, qkv):
         features = qkv.shape[-1]
@@ -105,27 +113,28 @@ class TransformerEncoder(layer.Layer):
     def forward(self, qkv):
         qkv = D.as_device(qkv)
         batch, seq_len_q, features = qkv.shape
-        if not (_identity_dropout(self._dropout1, self._dropout2)
-                and self._dense1._fused_relu()):
+        self._fused = _dropout_folds(features, self._dropout1, self._dropout2) and self._dense1._fused_relu()
+        if not self._fused:
             return self._forward_unfused(qkv)
         att, dense1, dense2 = self._self_attention, self._dense1, self._dense2
+        norm1, norm2 = self._norm1, self._norm2
         skip = qkv
         h = qkv
         if self._norm_first:
-            h = self._norm1(h)
+            h = norm1._forward_impl(h, self._dropout1)                   # dropout1 inside the norm (transformer.py:35-36)
         self._ensure(att, h)
         out = att._forward_impl(h, h, h, residual=skip)                  # ... + skip (transformer.py:39)
         if not self._norm_first:
-            out = self._norm1(out)
+            out = norm1._forward_impl(out, self._dropout1)               # transformer.py:40-41
         out = out.reshape(-1, features)
         skip = out
         if self._norm_first:
-            out = self._norm2(out)
+            out = norm2._forward_impl(out, self._dropout2)               # transformer.py:49-50
         out = dense1(out)
         self._ensure(dense2, out)
         out = dense2._forward_impl(out, residual=skip)                   # ... + skip (transformer.py:53)
         if not self._norm_first:
-            out = self._norm2(out)
+            out = norm2._forward_impl(out, self._dropout2)               # transformer.py:55-56
         self._pack()
         return out.reshape(batch, seq_len_q, features)
 
@@ -149,7 +158,7 @@ class TransformerEncoder(layer.Layer):
     def backward(self, dy, optimizer_):
         dy = D.as_device(dy)
         with parallel.grad_scope(self._numel(), self._arena) as scope:
-            if _identity_dropout(self._dropout1, self._dropout2) and self._dense1._fused_relu():
+            if self._fused and self._dense1._fused_relu():           # the composition the forward ran
                 return self._backward_fused(dy, optimizer_, scope)
             return self._backward_unfused(dy, optimizer_, scope)
 

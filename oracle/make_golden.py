@@ -110,9 +110,11 @@ def gen_mha(layers, batch, sq, skv, feat, heads, name):
          heads=np.int64(heads), lr=np.float64(0.01), **p0, **p1, **extra)
 
 
-def gen_encoder(layers, norm_first, name):
+def gen_encoder(layers, norm_first, name, drop_rate=0.0):
+    """drop_rate > 0: the masks the reference's DropOut layers drew from the global generator (in between the lazy parameter
+    draws of the first call) are stored too; a seeded run of the build must draw the very same ones."""
     np.random.seed(0)
-    enc = layers.TransformerEncoder(num_heads=4, hidden_units=96, norm_first=norm_first)
+    enc = layers.TransformerEncoder(num_heads=4, hidden_units=96, norm_first=norm_first, drop_rate=drop_rate)
     qkv = rand([3, 16, 48])
     out = enc(qkv)
     att = enc._self_attention
@@ -125,8 +127,12 @@ def gen_encoder(layers, norm_first, name):
     dy = rand(out.shape) * 0.05
     dx = enc(dy, backprop=True, learning_rate=1e-3)
     p1 = {k + '__1': getattr(o, a) for k, (o, a) in subs.items()}
+    extra = {}
+    if drop_rate:
+        extra = dict(drop_rate=np.float64(drop_rate), mask1=np.asarray(enc._dropout1._mask).astype(np.uint8),
+                     mask2=np.asarray(enc._dropout2._mask).astype(np.uint8))
     save(name, qkv=qkv, out=out, dy=dy, dx=dx, norm_first=np.bool_(norm_first),
-         heads=np.int64(4), hidden=np.int64(96), lr=np.float64(1e-3), **p0, **p1)
+         heads=np.int64(4), hidden=np.int64(96), lr=np.float64(1e-3), **p0, **p1, **extra)
 
 
 def gen_decoder(layers, norm_first, name):
@@ -315,6 +321,8 @@ def main():
     gen_mha(layers, 3, 10, 28, 48, 4, 'mha_cross')
     gen_encoder(layers, True, 'encoder_prenorm')
     gen_encoder(layers, False, 'encoder_postnorm')
+    gen_encoder(layers, True, 'encoder_dropout_prenorm', drop_rate=0.1)
+    gen_encoder(layers, False, 'encoder_dropout_postnorm', drop_rate=0.1)
     gen_decoder(layers, True, 'decoder_prenorm')
     gen_decoder(layers, False, 'decoder_postnorm')
     gen_losses(loss)

@@ -463,24 +463,30 @@ def _att_params(p):
 
 
 def encoder_fwd(p: Dict[str, Array], qkv: Array, norm_first: bool, eps: float = 1e-3,
-                eps2: Optional[float] = None, verbatim: bool = False):
-    """(transformer.py:29-59).  Returns (out, cache)."""
+                eps2: Optional[float] = None, verbatim: bool = False, drop=None):
+    """(transformer.py:29-59).  Returns (out, cache).  ``drop = (mask1, mask2, keep_prob)``: the masks DropOut drew
+    (transformer.py:35,40,49,55 -- always directly in front of a norm; normalizations.py:21-23), shapes [B,S,F] and [B S,F]."""
     eps2 = eps if eps2 is None else eps2
     b, s, f = qkv.shape
-    c: Dict[str, object] = {}
+    c: Dict[str, object] = {'drop': drop}
+    d1 = (lambda t: dropout_apply(t, drop[0].reshape(t.shape), drop[2])) if drop is not None else (lambda t: t)
+    d2 = (lambda t: dropout_apply(t, drop[1].reshape(t.shape), drop[2])) if drop is not None else (lambda t: t)
     skip = qkv
     h0 = qkv
     if norm_first:
+        h0 = d1(h0)
         c['n1_x'] = h0
         h0, c['n1'] = layernorm_fwd(h0, p['n1_gamma'], p['n1_beta'], eps)
     out, c['att'] = mha_fwd(_att_params(p), h0, verbatim=verbatim)
     out = out + skip
     if not norm_first:
+        out = d1(out)
         c['n1_x'] = out
         out, c['n1'] = layernorm_fwd(out, p['n1_gamma'], p['n1_beta'], eps)
     out = out.reshape(-1, f)
     skip = out
     if norm_first:
+        out = d2(out)
         c['n2_x'] = out
         out, c['n2'] = layernorm_fwd(out, p['n2_gamma'], p['n2_beta'], eps2)
     c['d1_x'] = out
@@ -489,6 +495,7 @@ def encoder_fwd(p: Dict[str, Array], qkv: Array, norm_first: bool, eps: float = 
     out = linear_fwd(out, p['d2_w'], p['d2_b'])
     out = out + skip
     if not norm_first:
+        out = d2(out)
         c['n2_x'] = out
         out, c['n2'] = layernorm_fwd(out, p['n2_gamma'], p['n2_beta'], eps2)
     return out.reshape(b, s, f), c
@@ -500,17 +507,23 @@ def encoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3,
     eps2 = eps if eps2 is None else eps2
     b, s, f = dy.shape
     g: Dict[str, Array] = {}
+    drop = c.get('drop')
+    d1 = (lambda t: dropout_apply(t, drop[0].reshape(t.shape), drop[2])) if drop is not None else (lambda t: t)    # normalizations.py:27-30
+    d2 = (lambda t: dropout_apply(t, drop[1].reshape(t.shape), drop[2])) if drop is not None else (lambda t: t)
     dy = dy.reshape(-1, f)
     if not norm_first:
         dy, g['n2_gamma'], g['n2_beta'] = layernorm_bwd(c['n2_x'], p['n2_gamma'], eps2, c['n2'], dy, verbatim)
+        dy = d2(dy)
     dskip = dy
     dy, g['d2_w'], g['d2_b'] = linear_bwd(c['d2_x'], p['d2_w'], dy)
     dy, g['d1_w'], g['d1_b'] = dense_bwd(c['d1_x'], p['d1_w'], c['d1_pre'], dy)
     if norm_first:
         dy, g['n2_gamma'], g['n2_beta'] = layernorm_bwd(c['n2_x'], p['n2_gamma'], eps2, c['n2'], dy, verbatim)
+        dy = d2(dy)
     dy = (dy + dskip).reshape(b, s, f)
     if not norm_first:
         dy, g['n1_gamma'], g['n1_beta'] = layernorm_bwd(c['n1_x'], p['n1_gamma'], eps, c['n1'], dy, verbatim)
+        dy = d1(dy)
     dskip = dy
     (dq, dk, dv), ga = mha_bwd(_att_params(p), c['att'], dy, verbatim=verbatim)
     for name, arr in ga.items():
@@ -518,6 +531,7 @@ def encoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3,
     dy = dq + dk + dv                                    # np.sum(tuple, axis=0), transformer.py:85
     if norm_first:
         dy, g['n1_gamma'], g['n1_beta'] = layernorm_bwd(c['n1_x'], p['n1_gamma'], eps, c['n1'], dy, verbatim)
+        dy = d1(dy)
     return dy + dskip, g
 
 

@@ -172,6 +172,7 @@ class HostSim:
         return 0
 
     def npm_add(self, a, b, out, n):
+        self.calls.append('npm_add')
         _vec(out, n)[:] = _vec(a, n) + _vec(b, n)
         return 0
 
@@ -237,6 +238,29 @@ class HostSim:
         _vec(dgamma, d)[:] = dg
         _vec(dbeta, d)[:] = db
         return 0
+
+    def _dropped(self, x, mask, keep, rows, d):
+        mk = np.ctypeslib.as_array((C.c_ubyte * int(rows * d)).from_address(_addr(mask))).reshape(rows, d) != 0
+        return mk, np.where(mk, _mat(x, rows, d, d) / np.float32(keep), np.float32(0)).astype(np.float32)
+
+    def npm_layernorm_dropout_fwd(self, x, mask, keep, gamma, beta, eps, rows, d, z, mean, rstd):
+        """include/npm_hip.h: npm_mask_scale, then npm_layernorm_fwd, without the tensor in between."""
+        self.calls.append('npm_layernorm_dropout_fwd')
+        assert d % 4 == 0 and d <= 4096 and _addr(mask) % 4 == 0
+        _, xd = self._dropped(x, mask, keep, rows, d)
+        return self.npm_layernorm_fwd(xd.ctypes.data, gamma, beta, eps, rows, d, z, mean, rstd)
+
+    def npm_layernorm_dropout_bwd(self, dz, x, mask, keep, mean, rstd, gamma, residual, rows, d, dx, dgamma, dbeta):
+        self.calls.append('npm_layernorm_dropout_bwd')
+        assert d % 4 == 0 and d <= 4096 and _addr(mask) % 4 == 0
+        mk, xd = self._dropped(x, mask, keep, rows, d)
+        inner = np.empty([rows, d], dtype=np.float32)
+        rc = self.npm_layernorm_bwd(dz, xd.ctypes.data, mean, rstd, gamma, 0, rows, d, inner.ctypes.data, dgamma, dbeta)
+        out = np.where(mk, inner / np.float32(keep), np.float32(0))
+        if _addr(residual):
+            out = out + _mat(residual, rows, d, d)
+        _mat(dx, rows, d, d)[:] = out
+        return rc
 
     # ---- fused attention core ------------------------------------------------------------------------
     def npm_mha_mask_summary(self, mask, sb, sh, sq_stride, nb, nh, seq_q, seq_kv, out):
@@ -391,14 +415,17 @@ class HostSim:
         return 0
 
     def npm_mask_scale(self, x, mask, y, n, keep):
+        self.calls.append('npm_mask_scale')
         mk = np.ctypeslib.as_array((C.c_ubyte * int(n)).from_address(_addr(mask)))
         _vec(y, n)[:] = np.where(mk != 0, _vec(x, n) / np.float32(keep), 0)
         return 0
 
     def npm_dropout_philox(self, x, y, mask, n, keep, seed, offset):
+        self.calls.append('npm_dropout_philox')
         keep_mask = O.dropout_philox_mask(int(n), float(keep), int(seed), int(offset))
         np.ctypeslib.as_array((C.c_ubyte * int(n)).from_address(_addr(mask)))[:] = keep_mask
-        _vec(y, n)[:] = np.where(keep_mask, _vec(x, n) * (np.float32(1.0) / np.float32(keep)), 0)
+        if _addr(y):                               # x = y = NULL: the mask only
+            _vec(y, n)[:] = np.where(keep_mask, _vec(x, n) / np.float32(keep), 0)
         return 0
 
     def npm_set_math(self, mode):

@@ -69,6 +69,71 @@ def test_encoder_golden(npm, name, math_mode):
         assert_close(v, g[k + '__1'], tol=1e-5, what=k)
 
 
+@pytest.mark.parametrize('name', ['encoder_dropout_prenorm', 'encoder_dropout_postnorm'])
+def test_encoder_with_dropout_golden(npm, name, math_mode):
+    """The reference's seeded run with drop_rate = 0.1 (transformer.py:13,22-23,35-36,40-41,49-50,55-56; masks from
+    np.random.binomial, normalizations.py:14-30): same seed -> the same parameters and the same masks, bit for bit; output,
+    dx and all 16 updated parameters match -- through the FUSED composition: each DropOut applied inside the LayerNorm
+    kernels behind it (npm_layernorm_dropout_fwd / _bwd), no mask pass, no standalone add."""
+    g = load_golden(name)
+    nf = bool(g['norm_first'])
+    np.random.seed(0)
+    enc = npm.layers.TransformerEncoder(num_heads=int(g['heads']), hidden_units=int(g['hidden']), norm_first=nf,
+                                        drop_rate=float(g['drop_rate']))
+    qkv = rand(g['qkv'].shape)
+    out = enc(qkv)
+    assert enc._fused
+    for k, v in _params(enc).items():
+        np.testing.assert_array_equal(v, g[k + '__0'], err_msg=k)
+    np.testing.assert_array_equal(np.asarray(enc._dropout1._mask), g['mask1'])
+    np.testing.assert_array_equal(np.asarray(enc._dropout2._mask), g['mask2'])
+    assert_close(out, g['out'], tol=1e-5)
+    dx = enc(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=1e-5)
+    for k, v in _params(enc).items():
+        assert_close(v, g[k + '__1'], tol=1e-5, what=k)
+
+
+@pytest.mark.parametrize('rows,d,residual', [(64, 1024, True), (37, 128, False), (5, 4096, True), (130, 72, True), (3, 2048, False)])
+def test_layernorm_dropout_kernels_equal_the_composed_calls(npm, rows, d, residual):
+    """npm_layernorm_dropout_fwd / _bwd (include/npm_hip.h) are bit-equal to npm_mask_scale -> npm_layernorm_fwd and
+    npm_layernorm_bwd -> npm_mask_scale (-> npm_add): z, mean, rstd, dx, dgamma, dbeta.  Row lengths the row-in-registers
+    kernels do not take are refused (the layer composes the calls then)."""
+    from np_modeling_amd import _C
+    D = npm.device
+    rng = np.random.default_rng(rows + d)
+    x = D.from_host(rng.standard_normal([rows, d]).astype(np.float32))
+    dz = D.from_host(rng.standard_normal([rows, d]).astype(np.float32))
+    res = D.from_host(rng.standard_normal([rows, d]).astype(np.float32)) if residual else None
+    gamma, beta = D.from_host(rng.standard_normal([d]).astype(np.float32)), D.from_host(rng.standard_normal([d]).astype(np.float32))
+    keep = 0.75
+    mask_host = (rng.random([rows, d]) < keep).astype(np.uint8)
+    mask = D.bytes_from_host(mask_host)
+    # composed
+    xd = D.empty([rows, d])
+    _C.check(_C.lib().npm_mask_scale(x.ptr, mask.ptr, xd.ptr, x.size, keep))
+    z0, mean0, rstd0 = D.layernorm_fwd(xd, gamma, beta, 1e-3)
+    dg0, db0 = D.empty([d]), D.empty([d])
+    inner = D.layernorm_bwd(dz, xd, mean0, rstd0, gamma, dg0, db0)
+    dx0 = D.empty([rows, d])
+    _C.check(_C.lib().npm_mask_scale(inner.ptr, mask.ptr, dx0.ptr, x.size, keep))
+    if residual:
+        dx0 = D.add(dx0, res)
+    # fused
+    z1, mean1, rstd1 = D.layernorm_fwd(x, gamma, beta, 1e-3, drop=(mask, keep))
+    dg1, db1 = D.empty([d]), D.empty([d])
+    dx1 = D.layernorm_bwd(dz, x, mean1, rstd1, gamma, dg1, db1, residual=res, drop=(mask, keep))
+    for a, b in ((z1, z0), (mean1, mean0), (rstd1, rstd0), (dx1, dx0), (dg1, dg0), (db1, db0)):
+        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    # against the definition
+    want = np.where(mask_host != 0, x.numpy() / np.float32(keep), np.float32(0))
+    wz, _ = O.layernorm_fwd(want.astype(np.float64), gamma.numpy().astype(np.float64), beta.numpy().astype(np.float64), 1e-3)
+    assert_close(z1, wz, tol=3e-6)
+    assert not D.layernorm_dropout_supported(70) and not D.layernorm_dropout_supported(8192)
+    with pytest.raises(_C.NpmError):
+        D.layernorm_fwd(D.zeros([4, 70]), D.zeros([70]), D.zeros([70]), 1e-3, drop=(D.bytes_from_host(np.ones([4, 70], dtype=np.uint8)), keep))
+
+
 @pytest.mark.parametrize('norm_first', [True, False])
 def test_encoder_reference_test_shape(npm, norm_first, math_mode):
     """B16, S32, F128, H8, U256 (reference layers/transformer_test.py:98-156), weights scaled

@@ -505,8 +505,12 @@ def test_decoder_slice(npm, norm_first):
 # counts, slab reduction, fused bias sums) against the oracle's arithmetic in fp64 at the real K: dw = x^T dy with
 # K = B S = 131 072 (reference layers/mlp.py:34-35, layers/attentions.py:167-188) and Conv2D's filter gradient with
 # K = 256 x 224 x 224 = 12.8 M pixels (layers/conv.py:54-56,185-194).  The fp64 side runs in chunks over K (bounded host
-# memory); tolerance: the GEMM tests' metric, |got - ref| <= tol (|ref| + max |ref|).
-FULL_K_TOL = {'f32': 2e-6, 'bf16x3': 2e-6, 'f16x2': 2e-6}
+# memory); metric: the GEMM tests', |got - ref| <= tol (|ref| + max |ref|).  Tolerance: the SCALED bound of the parity contract
+# (include/npm_hip.h NPM_PARITY_SCALED_*, 1e-5), not the 2e-6 of the short-K GEMM tests: an fp32 accumulator that takes
+# 43 691 products in a row (K / 3 splits) carries eps * n / sqrt(2) of a term's magnitude -- measured 7.8e-6 of the largest
+# element for dense1's dw in the exact-f32 mode (profiles/r06_full_k_weight_gradients.log); the split modes add 16 products per
+# step and sit lower.  (The reference's own sgemm accumulates in fp32 too: reference layers/mlp.py:35.)
+FULL_K_TOL = {'f32': 1e-5, 'bf16x3': 1e-5, 'f16x2': 1e-5}
 
 
 @pytest.mark.parametrize('m,n,which', [(1024, 4096, 'bsum'), (4096, 1024, 'bsum'), (3072, 1024, 'asum'), (1024, 1024, 'asum')])
@@ -582,8 +586,8 @@ def test_conv_c3_filter_gradient_at_full_size_against_fp64(npm):
                 want_b += g.sum(axis=(0, 1, 2))
             print(f'C3 full dw {mode}: scaled error {np.abs(got["_w"] - want_w).max() / np.abs(want_w).max():.2e}, '
                   f'db {np.abs(got["_b"] - want_b).max() / np.abs(want_b).max():.2e}')
-            assert_close(got['_w'], want_w, tol=2e-6, what=f'{mode} dw, all {n} samples')
-            assert_close(got['_b'], want_b, tol=2e-6, what=f'{mode} db, all {n} samples')
+            assert_close(got['_w'], want_w, tol=FULL_K_TOL[mode], what=f'{mode} dw, all {n} samples')
+            assert_close(got['_b'], want_b, tol=FULL_K_TOL[mode], what=f'{mode} db, all {n} samples')
             del pre
     finally:
         npm.set_math('f32')

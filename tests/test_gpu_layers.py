@@ -219,7 +219,7 @@ def test_dropout_device_rng(npm, shape, p):
         y = np.asarray(d(x))
         want_mask = O.dropout_philox_mask(x.size, keep, 0x1234567811223344, 0).reshape(shape)
         np.testing.assert_array_equal(d._mask != 0, want_mask)
-        np.testing.assert_array_equal(y, np.where(want_mask, x * (np.float32(1) / np.float32(keep)), 0).astype(np.float32))
+        np.testing.assert_array_equal(y, np.where(want_mask, x / np.float32(keep), 0).astype(np.float32))      # normalizations.py:23: x / keep_prob
         dy = rng.standard_normal(shape).astype(np.float32)
         np.testing.assert_array_equal(np.asarray(d.backward(dy)),
                                       np.where(want_mask, dy / np.float32(keep), 0).astype(np.float32))
@@ -239,8 +239,8 @@ def test_dropout_device_rng(npm, shape, p):
 
 
 def test_encoder_with_device_dropout(npm):
-    """drop_rate > 0 inside the encoder takes the literal (unfused) composition; with device-drawn masks the step
-    equals the oracle's encoder evaluated with those very masks."""
+    """drop_rate > 0 inside the encoder (fused composition: the dropouts ride inside the LayerNorm kernels) with
+    device-drawn masks: the step equals the oracle's encoder evaluated with those very masks."""
     rng = np.random.default_rng(2)
     x = rng.standard_normal([2, 12, 32]).astype(np.float32)
     dy = rng.standard_normal([2, 12, 32]).astype(np.float32)
@@ -263,17 +263,11 @@ def test_encoder_with_device_dropout(npm):
         p[tag + '_gamma'], p[tag + '_beta'] = (np.asarray(getattr(norm, a)).astype(np.float64) for a in ('_gamma', '_beta'))
     p['d1_w'], p['d1_b'] = (np.asarray(getattr(enc._dense1.linear, a)).astype(np.float64) for a in ('_w', '_b'))
     p['d2_w'], p['d2_b'] = (np.asarray(getattr(enc._dense2, a)).astype(np.float64) for a in ('_w', '_b'))
-    x64 = x.astype(np.float64)
-    h1 = O.dropout_apply(x64, m1, 0.8)
-    z1, c1 = O.layernorm_fwd(h1, p['n1_gamma'], p['n1_beta'], 1e-3)
-    a_out, _ = O.mha_fwd({n: p['att_' + n] for n in O.MHA_PARAM_NAMES}, z1)
-    s1 = (a_out + x64).reshape(24, 32)
-    h2 = O.dropout_apply(s1, m2, 0.8)
-    z2, _ = O.layernorm_fwd(h2, p['n2_gamma'], p['n2_beta'], 1e-3)
-    hid, _ = O.dense_fwd(z2, p['d1_w'], p['d1_b'])
-    want = (O.linear_fwd(hid, p['d2_w'], p['d2_b']) + s1).reshape(2, 12, 32)
+    want, cache = O.encoder_fwd(p, x.astype(np.float64), True, drop=(m1, m2, 0.8))
     assert_close(out, want, tol=1e-5)
-    assert np.isfinite(dx).all()
+    want_dx, _ = O.encoder_bwd(p, cache, dy.astype(np.float64), True)
+    assert_close(dx, want_dx, tol=1e-5)
+    assert enc._fused
 
 
 # ---- MultiHeadAttention ------------------------------------------------------------------------

@@ -84,6 +84,31 @@ def test_encoder_composition_on_simulator(npm, name):
     assert_close(enc._norm1._gamma, g['n1_gamma__1'], tol=1e-5)
 
 
+@pytest.mark.parametrize('name', ['encoder_dropout_prenorm', 'encoder_dropout_postnorm'])
+def test_encoder_with_dropout_reproduces_the_reference_run(npm, name):
+    """The reference's own seeded run with drop_rate = 0.1 (tests/golden/encoder_dropout_*.npz, written by oracle/make_golden.py
+    from the real reference): the same seed draws the same parameters AND the same masks (np.random.binomial at its place in
+    the lazy-initialisation order), and output, input gradient and updated parameters follow -- through the fused
+    composition (dropout inside the LayerNorm kernels)."""
+    g = load_golden(name)
+    np.random.seed(0)
+    enc = npm.layers.TransformerEncoder(num_heads=int(g['heads']), hidden_units=int(g['hidden']),
+                                        norm_first=bool(g['norm_first']), drop_rate=float(g['drop_rate']))
+    del npm._C._LIB.calls[:]
+    out = enc(rand(g['qkv'].shape))
+    assert enc._fused and npm._C._LIB.calls.count('npm_layernorm_dropout_fwd') == 2
+    np.testing.assert_array_equal(np.asarray(enc._dropout1._mask), g['mask1'])
+    np.testing.assert_array_equal(np.asarray(enc._dropout2._mask), g['mask2'])
+    np.testing.assert_array_equal(np.asarray(enc._norm2._gamma), g['n2_gamma__0'])
+    assert_close(out, g['out'], tol=1e-5)
+    dx = enc(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dx, g['dx'], tol=1e-5)
+    assert_close(enc._dense2.w, g['d2_w__1'], tol=1e-5)
+    assert_close(enc._self_attention._wq, g['att_wq__1'], tol=1e-5)
+    assert_close(enc._norm1._gamma, g['n1_gamma__1'], tol=1e-5)
+    assert_close(enc._norm2._beta, g['n2_beta__1'], tol=1e-5)
+
+
 @pytest.mark.parametrize('name', ['decoder_prenorm', 'decoder_postnorm'])
 def test_decoder_fused_composition_on_simulator(npm, name):
     """The fused decoder composition (seeded draw order, residual / sum epilogues, the (dq, dkv) tuple) against the
@@ -364,6 +389,52 @@ def test_deepcopy_after_packed_forward(npm):
     twin = copy.deepcopy(enc)
     np.testing.assert_array_equal(np.asarray(twin(dy, backprop=True, learning_rate=0.1)),
                                   np.asarray(enc(dy, backprop=True, learning_rate=0.1)))
+
+
+@pytest.mark.parametrize('norm_first', [True, False])
+@pytest.mark.parametrize('rng_kind', ['host', 'device'])
+def test_encoder_dropout_rides_inside_the_layernorm_kernels(npm, norm_first, rng_kind):
+    """drop_rate > 0 (reference transformer.py:13,22-23,35-36,40-41,49-50,55-56): the encoder keeps its fused composition --
+    each DropOut is applied inside the LayerNorm kernels behind it (npm_layernorm_dropout_fwd / _bwd), no standalone
+    mask pass or add runs -- and equals the literal composition (DropOut layer -> norm -> ... -> add) on the same masks:
+    outputs, input gradient, all 16 parameters after the step, and the readable ``_mask`` of both dropouts.  Host-drawn
+    masks consume the global generator exactly as the literal order does (mask first, then a norm's lazy parameters)."""
+    sim = npm._C._LIB
+    x, dy = rand([3, 6, 8]), rand([3, 6, 8])
+
+    def run(fused):
+        np.random.seed(11)
+        if rng_kind == 'device':
+            npm.set_dropout_rng('device', seed=77)
+        enc = npm.layers.TransformerEncoder(num_heads=2, hidden_units=12, norm_first=norm_first, drop_rate=0.3)
+        if not fused:
+            enc._dense1._fused_relu = lambda: False                      # sends forward / backward to the literal composition
+        del sim.calls[:]
+        out = np.asarray(enc(x))
+        fwd_calls = list(sim.calls)
+        masks = [np.asarray(enc._dropout1._mask).copy(), np.asarray(enc._dropout2._mask).copy()]
+        del sim.calls[:]
+        dx = np.asarray(enc(dy, backprop=True, learning_rate=0.05))
+        bwd_calls = list(sim.calls)
+        from np_modeling_amd import parallel
+        return out, dx, masks, [np.asarray(p).copy() for p in parallel.parameters(enc)], fwd_calls, bwd_calls
+
+    try:
+        out_f, dx_f, masks_f, params_f, fwd_calls, bwd_calls = run(True)
+        out_u, dx_u, masks_u, params_u, ufwd, ubwd = run(False)
+    finally:
+        npm.set_dropout_rng('host')
+    assert fwd_calls.count('npm_layernorm_dropout_fwd') == 2 and bwd_calls.count('npm_layernorm_dropout_bwd') == 2
+    assert 'npm_mask_scale' not in fwd_calls + bwd_calls and 'npm_add' not in fwd_calls + bwd_calls
+    assert 'npm_layernorm_dropout_fwd' not in ufwd and ('npm_mask_scale' in ufwd or 'npm_dropout_philox' in ufwd)
+    for a, b in zip(masks_f, masks_u):
+        assert 0 < (a != 0).mean() < 1
+        np.testing.assert_array_equal(a != 0, b != 0)
+    np.testing.assert_allclose(out_f, out_u, rtol=2e-6, atol=2e-6)
+    np.testing.assert_allclose(dx_f, dx_u, rtol=2e-5, atol=2e-6)
+    assert len(params_f) == len(params_u) == 16
+    for a, b in zip(params_f, params_u):
+        np.testing.assert_allclose(a, b, rtol=2e-5, atol=2e-6)
 
 
 def test_deepcopy_owns_its_device_blocks(npm):

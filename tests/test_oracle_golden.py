@@ -112,6 +112,32 @@ def test_encoder(name, verbatim):
         close_scaled(O.sgd_step(p[k], grad, float(g['lr'])), g[k + '__1'])
 
 
+@pytest.mark.parametrize('name', ['encoder_dropout_prenorm', 'encoder_dropout_postnorm'])
+@pytest.mark.parametrize('verbatim', [True, False])
+def test_encoder_with_dropout(name, verbatim):
+    """drop_rate = 0.1 (reference transformer.py:13,22-23 and normalizations.py:14-30): with the masks the reference drew, the
+    oracle reproduces its output, input gradient and every updated parameter."""
+    g = load_golden(name)
+    nf = bool(g['norm_first'])
+    p = {k[:-3]: v for k, v in g.items() if k.endswith('__0')}
+    drop = (g['mask1'], g['mask2'], 1.0 - float(g['drop_rate']))
+    assert 0.8 < g['mask1'].mean() < 0.97 and g['mask2'].shape == (g['qkv'].shape[0] * g['qkv'].shape[1], g['qkv'].shape[2])
+    out, cache = O.encoder_fwd(p, g['qkv'], nf, verbatim=verbatim, drop=drop)
+    close_scaled(out, g['out'])
+    dx, grads = O.encoder_bwd(p, cache, g['dy'], nf, verbatim=verbatim)
+    close_scaled(dx, g['dx'])
+    for k, grad in grads.items():
+        close_scaled(O.sgd_step(p[k], grad, float(g['lr'])), g[k + '__1'])
+    # and the masks are the global generator's draws at their place in the lazy-initialisation order
+    np.random.seed(0)
+    qkv = np.random.normal(size=g['qkv'].shape).astype(np.float32)
+    np.testing.assert_array_equal(qkv, g['qkv'])
+    keep = 1.0 - float(g['drop_rate'])
+    if nf:                                   # pre-norm: dropout1 runs first of all (transformer.py:35), then norm1 draws gamma, beta
+        m1 = np.random.binomial(n=1, p=keep, size=qkv.size).reshape(qkv.shape)
+        np.testing.assert_array_equal(m1, g['mask1'])
+
+
 @pytest.mark.parametrize('norm_first', [True, False])
 def test_encoder_init_draw_order(norm_first):
     """Seeded param draws reproduce the reference's lazy-initialisation order."""

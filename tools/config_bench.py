@@ -22,8 +22,9 @@ import numpy as np  # noqa: E402
 PEAK = 157.3
 MIN_SECONDS = 0.5
 NAMES = ('C2', 'C3', 'C4')
-EXTRA = ('DEC', 'C4M', 'C4D64')   # not BASELINE.json configs (`--only NAME`): TransformerDecoder at size; C4 under a
-#                                 causal mask (the tile summary at work); C4's dimensions with 16 heads of 64
+EXTRA = ('DEC', 'C4M', 'C4D64', 'C5D', 'C5')   # not BASELINE.json configs (`--only NAME`): TransformerDecoder at size; C4 under a
+#                                 causal mask (the tile summary at work); C4's dimensions with 16 heads of 64; the headline encoder shard with
+#                                 drop_rate 0.1 (device-drawn masks, applied inside the LayerNorm kernels) and, for an in-session twin, without
 
 
 def timed(fn, steps, D, min_seconds=None, kernels=False):
@@ -117,6 +118,29 @@ def build_config(name, npm, D, rng, conv_batch=256):
             layer(x, mask=mask)
             layer(dy, backprop=True, optimizer_=sgd)
         return label, b, flops, step_masked
+    elif name in ('C5D', 'C5'):
+        # the headline workload (bench.py: per-GPU shard of BASELINE.json configs[4]) in this harness; C5D with dropout
+        # (reference transformer.py:13,22-23: drop_rate is a constructor argument of the encoder)
+        import bench
+        b, s, f, h, u = 256, 512, 1024, 8, 4096
+        rate = 0.1 if name == 'C5D' else 0.0
+        layer = npm.layers.TransformerEncoder(num_heads=h, hidden_units=u, norm_first=True, drop_rate=rate)
+        x = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32))
+        dy = D.from_host(rng.standard_normal([b, s, f], dtype=np.float32) * np.float32(0.01))
+        if rate:
+            npm.set_dropout_rng('device', seed=2024)        # masks drawn on the GPU (Philox4x32-10); 'host' = the reference's np.random.binomial
+        layer(D.from_host(np.zeros([1, 8, f], dtype=np.float32)))
+        bench.bind(layer, bench.make_params(np.random.default_rng(0), f, h, u))
+        label = (f'TransformerEncoder d_model={f} heads={h} seq={s} hidden={u} pre-norm fwd+bwd+SGD, batch {b}' +
+                 (f', drop_rate {rate} (device-drawn masks: two Philox mask launches per step, both DropOuts applied inside the '
+                  'LayerNorm kernels behind them)' if rate else ' (bench.py\'s headline workload in this harness)') +
+                 ' (not a BASELINE.json config)')
+        flops = b * bench.encoder_flops_per_sample(s, f, h, u)
+
+        def step_enc():
+            layer(x)
+            layer(dy, backprop=True, optimizer_=sgd)
+        return label, b, flops, step_enc
     elif name == 'DEC':
         b, sq, skv, f, h, u = 64, 512, 1024, 1024, 8, 4096
         layer = npm.layers.TransformerDecoder(num_heads=h, hidden_units=u, norm_first=True)
@@ -153,7 +177,10 @@ def build_config(name, npm, D, rng, conv_batch=256):
 def run_config(name, npm, D, steps=3, min_seconds=None, kernels=True, conv_batch=256):
     """One config -> the dict bench.py puts under ``configs[name]``."""
     label, batch, flops, step = build_config(name, npm, D, np.random.default_rng(0), conv_batch)
-    sec, steps, summary = timed(step, steps, D, min_seconds, kernels)
+    try:
+        sec, steps, summary = timed(step, steps, D, min_seconds, kernels)
+    finally:
+        npm.set_dropout_rng('host')
     out = {'workload': label, 'value': batch / sec, 'unit': 'samples/s', 'ms_per_step': 1e3 * sec, 'steps': steps,
            'tflops': flops / sec / 1e12, 'frac_of_fp32_mfma_peak': flops / sec / 1e12 / PEAK, 'math': npm._C.current_math()}
     if summary:
