@@ -232,8 +232,9 @@ int npm_layernorm_bwd(const float *dz, const float *x, const float *mean, const 
  *   forward   xd = mask ? x / keep_prob : 0 (normalizations.py:21-23) on the way in, then npm_layernorm_fwd's arithmetic on xd;
  *   backward  the same xd again from x and mask, npm_layernorm_bwd's arithmetic, then DropOut.backward on the way out
  *             (normalizations.py:27-30): dx = mask ? dxd / keep_prob : 0 [+ residual].
- * mask: one byte per element (0 = dropped), 4-byte aligned.  Bit-equal to npm_mask_scale + npm_layernorm_fwd / npm_layernorm_bwd +
- * npm_mask_scale (+ npm_add).  Rows with d % 4 != 0 or d > 4096 are NPM_E_UNSUPPORTED: compose the calls above. */
+ * mask: one byte per element (0 = dropped), 4-byte aligned.  Equal to npm_mask_scale + npm_layernorm_fwd / npm_layernorm_bwd +
+ * npm_mask_scale (+ npm_add) to rounding (the same operations in the same order; the compiler contracts the row sums of products
+ * into fused multiply-adds per kernel instance: single ulps in a few per cent of dx).  Rows with d % 4 != 0 or d > 4096 are NPM_E_UNSUPPORTED: compose the calls above. */
 int npm_layernorm_dropout_fwd(const float *x, const unsigned char *mask, float keep_prob, const float *gamma, const float *beta,
                               float eps, int64_t rows, int64_t d, float *z, float *mean, float *rstd);
 int npm_layernorm_dropout_bwd(const float *dz, const float *x, const unsigned char *mask, float keep_prob, const float *mean,

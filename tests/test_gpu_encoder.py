@@ -96,8 +96,8 @@ def test_encoder_with_dropout_golden(npm, name, math_mode):
 
 @pytest.mark.parametrize('rows,d,residual', [(64, 1024, True), (37, 128, False), (5, 4096, True), (130, 72, True), (3, 2048, False)])
 def test_layernorm_dropout_kernels_equal_the_composed_calls(npm, rows, d, residual):
-    """npm_layernorm_dropout_fwd / _bwd (include/npm_hip.h) are bit-equal to npm_mask_scale -> npm_layernorm_fwd and
-    npm_layernorm_bwd -> npm_mask_scale (-> npm_add): z, mean, rstd, dx, dgamma, dbeta.  Row lengths the row-in-registers
+    """npm_layernorm_dropout_fwd / _bwd (include/npm_hip.h) equal npm_mask_scale -> npm_layernorm_fwd and
+    npm_layernorm_bwd -> npm_mask_scale (-> npm_add) to rounding: z, mean, rstd, dx, dgamma, dbeta.  Row lengths the row-in-registers
     kernels do not take are refused (the layer composes the calls then)."""
     from np_modeling_amd import _C
     D = npm.device
@@ -123,8 +123,11 @@ def test_layernorm_dropout_kernels_equal_the_composed_calls(npm, rows, d, residu
     z1, mean1, rstd1 = D.layernorm_fwd(x, gamma, beta, 1e-3, drop=(mask, keep))
     dg1, db1 = D.empty([d]), D.empty([d])
     dx1 = D.layernorm_bwd(dz, x, mean1, rstd1, gamma, dg1, db1, residual=res, drop=(mask, keep))
-    for a, b in ((z1, z0), (mean1, mean0), (rstd1, rstd0), (dx1, dx0), (dg1, dg0), (db1, db0)):
-        np.testing.assert_array_equal(a.numpy(), b.numpy())
+    # (not bitwise: the row sums  sum g yhat  / sum (x - mean)^2  are sums of products, which hipcc contracts into fused multiply-adds
+    #  its own way in every template instance -- measured: 3 % of dx one ulp apart at [64, 1024])
+    for name, a, b in (('z', z1, z0), ('mean', mean1, mean0), ('rstd', rstd1, rstd0), ('dx', dx1, dx0), ('dgamma', dg1, dg0), ('dbeta', db1, db0)):
+        assert_close(a.numpy(), b.numpy(), tol=5e-7, what=name)
+    np.testing.assert_array_equal(dx1.numpy()[mask_host == 0], res.numpy()[mask_host == 0] if residual else 0)    # dropped positions: exactly the residual
     # against the definition
     want = np.where(mask_host != 0, x.numpy() / np.float32(keep), np.float32(0))
     wz, _ = O.layernorm_fwd(want.astype(np.float64), gamma.numpy().astype(np.float64), beta.numpy().astype(np.float64), 1e-3)
