@@ -233,8 +233,12 @@ class TransformerDecoder(layer.Layer):
             sub.initialize(*args)
             sub._initialized = True
 
-    def _fusable(self) -> bool:
-        return _identity_dropout(self._dropout1, self._dropout2, self._dropout3) and self._dense1._fused_relu()
+    _fused = True          # which composition the last forward ran (the backward mirrors it)
+
+    def _fusable(self, features: int = 0) -> bool:
+        """The fused composition: always without dropout; with dropout when the LayerNorm kernels can apply it (row
+        length: device.layernorm_dropout_supported)."""
+        return _dropout_folds(features, self._dropout1, self._dropout2, self._dropout3) and self._dense1._fused_relu()
 
     def _numel(self) -> int:
         """Floats the gradients of one backward need (26 parameter tensors): ONE bucket for the exchange, like the
@@ -255,33 +259,36 @@ class TransformerDecoder(layer.Layer):
 
     def forward(self, q, kv):
         """Three residual blocks: self-attention, cross-attention over ``kv``, feed-forward (transformer.py:120-157).
-        Without dropout the residual additions ride the producing GEMMs' epilogues, as in the encoder."""
+        The residual additions ride the producing GEMMs' epilogues and the dropouts the LayerNorm kernels, as in the encoder."""
         q, kv = D.as_device(q), D.as_device(kv)
-        if not self._fusable():
-            return self._forward_unfused(q, kv)
         batch, seq_len_q, features = q.shape
+        self._fused = self._fusable(features)
+        if not self._fused:
+            return self._forward_unfused(q, kv)
         pre = self._norm_first
         sa, ca, dense1, dense2 = self._self_attention, self._cross_attention, self._dense1, self._dense2
         self._kv = kv
-        h = self._norm1(q) if pre else q
+        # each DropOut sits directly in front of a LayerNormalization (transformer.py:125-126,131-132,137-138,142-143,
+        # 149-150,154-155) and is applied inside that norm's kernels
+        h = self._norm1._forward_impl(q, self._dropout1) if pre else q
         self._ensure(sa, h)
         out = sa._forward_impl(h, h, h, residual=q)                       # ... + skip (transformer.py:130)
         if not pre:
-            out = self._norm1(out)
+            out = self._norm1._forward_impl(out, self._dropout1)
         skip = out
-        h = self._norm2(out) if pre else out
+        h = self._norm2._forward_impl(out, self._dropout2) if pre else out
         self._ensure(ca, h, kv)
         out = ca._forward_impl(h, kv, kv, residual=skip)                  # ... + skip (transformer.py:141)
         if not pre:
-            out = self._norm2(out)
+            out = self._norm2._forward_impl(out, self._dropout2)
         out = out.reshape(-1, features)
         skip = out
-        h = self._norm3(out) if pre else out
+        h = self._norm3._forward_impl(out, self._dropout3) if pre else out
         h = dense1(h)
         self._ensure(dense2, h)
         out = dense2._forward_impl(h, residual=skip)                      # ... + skip (transformer.py:152)
         if not pre:
-            out = self._norm3(out)
+            out = self._norm3._forward_impl(out, self._dropout3)
         self._pack()
         return out.reshape(batch, seq_len_q, features)
 
@@ -299,7 +306,7 @@ class TransformerDecoder(layer.Layer):
         """Returns ``(dq, dkv)``; ``dkv`` is the cross-attention's dkey + dvalue (transformer.py:159-203)."""
         dy = D.as_device(dy)
         with parallel.grad_scope(self._numel(), self._arena) as scope:
-            if self._fusable():
+            if self._fused and self._dense1._fused_relu():           # the composition the forward ran
                 return self._backward_fused(dy, optimizer_, scope)
             return self._backward_unfused(dy, optimizer_, scope)
 

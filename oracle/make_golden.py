@@ -135,9 +135,9 @@ def gen_encoder(layers, norm_first, name, drop_rate=0.0):
          heads=np.int64(4), hidden=np.int64(96), lr=np.float64(1e-3), **p0, **p1, **extra)
 
 
-def gen_decoder(layers, norm_first, name):
+def gen_decoder(layers, norm_first, name, drop_rate=0.0):
     np.random.seed(0)
-    dec = layers.TransformerDecoder(num_heads=4, hidden_units=80, norm_first=norm_first)
+    dec = layers.TransformerDecoder(num_heads=4, hidden_units=80, norm_first=norm_first, drop_rate=drop_rate)
     q = rand([3, 12, 48])
     kv = rand([3, 20, 48])
     out = dec(q, kv)
@@ -153,8 +153,12 @@ def gen_decoder(layers, norm_first, name):
     dy = rand(out.shape) * 0.05
     dq, dkv = dec(dy, backprop=True, learning_rate=1e-3)
     p1 = {k + '__1': getattr(o, a) for k, (o, a) in subs.items()}
+    extra = {}
+    if drop_rate:
+        extra = dict(drop_rate=np.float64(drop_rate), **{f'mask{i}': np.asarray(d._mask).astype(np.uint8)
+                                                        for i, d in enumerate([dec._dropout1, dec._dropout2, dec._dropout3], start=1)})
     save(name, q=q, kv=kv, out=out, dy=dy, dq=dq, dkv=dkv, norm_first=np.bool_(norm_first), heads=np.int64(4),
-         hidden=np.int64(80), lr=np.float64(1e-3), **p0, **p1)
+         hidden=np.int64(80), lr=np.float64(1e-3), **p0, **p1, **extra)
 
 
 def gen_losses(loss):
@@ -325,6 +329,8 @@ def main():
     gen_encoder(layers, False, 'encoder_dropout_postnorm', drop_rate=0.1)
     gen_decoder(layers, True, 'decoder_prenorm')
     gen_decoder(layers, False, 'decoder_postnorm')
+    gen_decoder(layers, True, 'decoder_dropout_prenorm', drop_rate=0.1)
+    gen_decoder(layers, False, 'decoder_dropout_postnorm', drop_rate=0.1)
     gen_losses(loss)
     gen_softmax_ce(layers, loss)
     gen_train(layers, optimizer, train)

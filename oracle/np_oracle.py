@@ -543,33 +543,40 @@ def _att(p, tag):
 
 
 def decoder_fwd(p: Dict[str, Array], q: Array, kv: Array, norm_first: bool, eps: float = 1e-3,
-                verbatim: bool = False):
+                verbatim: bool = False, drop=None):
     """Self-attention, cross-attention over kv, feed-forward (transformer.py:117-158).
-    Params: sa_*, ca_* (attention), n1/n2/n3_{gamma,beta}, d1_w/b, d2_w/b."""
+    Params: sa_*, ca_* (attention), n1/n2/n3_{gamma,beta}, d1_w/b, d2_w/b.  ``drop = (mask1, mask2, mask3, keep_prob)``: the
+    masks the three DropOuts drew (each directly in front of its norm, transformer.py:125,131,137,142,149,154)."""
     b, s, f = q.shape
-    c: Dict[str, object] = {}
+    c: Dict[str, object] = {'drop': drop}
+    dr = [(lambda t, m=m: dropout_apply(t, m.reshape(t.shape), drop[3])) for m in drop[:3]] if drop is not None else [lambda t: t] * 3
     skip = q
     h = q
     if norm_first:
+        h = dr[0](h)
         c['n1_x'] = h
         h, c['n1'] = layernorm_fwd(h, p['n1_gamma'], p['n1_beta'], eps)
     out, c['sa'] = mha_fwd(_att(p, 'sa'), h, verbatim=verbatim)
     out = out + skip
     if not norm_first:
+        out = dr[0](out)
         c['n1_x'] = out
         out, c['n1'] = layernorm_fwd(out, p['n1_gamma'], p['n1_beta'], eps)
     skip = out
     if norm_first:
+        out = dr[1](out)
         c['n2_x'] = out
         out, c['n2'] = layernorm_fwd(out, p['n2_gamma'], p['n2_beta'], eps)
     out, c['ca'] = mha_fwd(_att(p, 'ca'), out, kv, verbatim=verbatim)
     out = out + skip
     if not norm_first:
+        out = dr[1](out)
         c['n2_x'] = out
         out, c['n2'] = layernorm_fwd(out, p['n2_gamma'], p['n2_beta'], eps)
     out = out.reshape(-1, f)
     skip = out
     if norm_first:
+        out = dr[2](out)
         c['n3_x'] = out
         out, c['n3'] = layernorm_fwd(out, p['n3_gamma'], p['n3_beta'], eps)
     c['d1_x'] = out
@@ -577,6 +584,7 @@ def decoder_fwd(p: Dict[str, Array], q: Array, kv: Array, norm_first: bool, eps:
     c['d2_x'] = out
     out = linear_fwd(out, p['d2_w'], p['d2_b']) + skip
     if not norm_first:
+        out = dr[2](out)
         c['n3_x'] = out
         out, c['n3'] = layernorm_fwd(out, p['n3_gamma'], p['n3_beta'], eps)
     return out.reshape(b, s, f), c
@@ -586,17 +594,22 @@ def decoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3, verbatim: 
     """Returns ((dq, dkv), grads); dkv = dkey + dvalue of the cross-attention (transformer.py:160-203)."""
     b, s, f = dy.shape
     g: Dict[str, Array] = {}
+    drop = c.get('drop')
+    dr = [(lambda t, m=m: dropout_apply(t, m.reshape(t.shape), drop[3])) for m in drop[:3]] if drop is not None else [lambda t: t] * 3
     dy = dy.reshape(-1, f)
     if not norm_first:
         dy, g['n3_gamma'], g['n3_beta'] = layernorm_bwd(c['n3_x'], p['n3_gamma'], eps, c['n3'], dy, verbatim)
+        dy = dr[2](dy)
     dskip = dy
     dy, g['d2_w'], g['d2_b'] = linear_bwd(c['d2_x'], p['d2_w'], dy)
     dy, g['d1_w'], g['d1_b'] = dense_bwd(c['d1_x'], p['d1_w'], c['d1_pre'], dy)
     if norm_first:
         dy, g['n3_gamma'], g['n3_beta'] = layernorm_bwd(c['n3_x'], p['n3_gamma'], eps, c['n3'], dy, verbatim)
+        dy = dr[2](dy)
     dy = (dy + dskip).reshape(b, s, f)
     if not norm_first:
         dy, g['n2_gamma'], g['n2_beta'] = layernorm_bwd(c['n2_x'], p['n2_gamma'], eps, c['n2'], dy, verbatim)
+        dy = dr[1](dy)
     dskip = dy
     (dq, dk, dv), ga = mha_bwd(_att(p, 'ca'), c['ca'], dy, verbatim=verbatim)
     for name, arr in ga.items():
@@ -605,9 +618,11 @@ def decoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3, verbatim: 
     dy = dq
     if norm_first:
         dy, g['n2_gamma'], g['n2_beta'] = layernorm_bwd(c['n2_x'], p['n2_gamma'], eps, c['n2'], dy, verbatim)
+        dy = dr[1](dy)
     dy = dy + dskip
     if not norm_first:
         dy, g['n1_gamma'], g['n1_beta'] = layernorm_bwd(c['n1_x'], p['n1_gamma'], eps, c['n1'], dy, verbatim)
+        dy = dr[0](dy)
     dskip = dy
     (dq, dk, dv), ga = mha_bwd(_att(p, 'sa'), c['sa'], dy, verbatim=verbatim)
     for name, arr in ga.items():
@@ -615,6 +630,7 @@ def decoder_bwd(p, c, dy: Array, norm_first: bool, eps: float = 1e-3, verbatim: 
     dy = dq + dk + dv
     if norm_first:
         dy, g['n1_gamma'], g['n1_beta'] = layernorm_bwd(c['n1_x'], p['n1_gamma'], eps, c['n1'], dy, verbatim)
+        dy = dr[0](dy)
     return (dy + dskip, dkv), g
 
 

@@ -229,6 +229,30 @@ def test_decoder_golden(npm, name, math_mode):
         assert_close(getattr(_sub(dec, path), attr), g[k + '__1'], tol=1e-4, what=k)
 
 
+@pytest.mark.parametrize('name', ['decoder_dropout_prenorm', 'decoder_dropout_postnorm'])
+def test_decoder_with_dropout_golden(npm, name, math_mode):
+    """The reference's seeded decoder run with drop_rate = 0.1 (transformer.py:98,111-113; normalizations.py:14-30): same seed
+    -> the same 26 parameters and the same three masks bit for bit, then output, (dq, dkv) and all updated parameters --
+    through the fused composition (the dropouts inside the LayerNorm kernels)."""
+    g = load_golden(name)
+    np.random.seed(0)
+    dec = npm.layers.TransformerDecoder(num_heads=int(g['heads']), hidden_units=int(g['hidden']),
+                                        norm_first=bool(g['norm_first']), drop_rate=float(g['drop_rate']))
+    q, kv = rand(g['q'].shape), rand(g['kv'].shape)
+    out = dec(q, kv)
+    assert dec._fused
+    for k, (path, attr) in _DEC.items():
+        np.testing.assert_array_equal(np.asarray(getattr(_sub(dec, path), attr)), g[k + '__0'], err_msg=k)
+    for i, d in enumerate((dec._dropout1, dec._dropout2, dec._dropout3), start=1):
+        np.testing.assert_array_equal(np.asarray(d._mask), g[f'mask{i}'])
+    assert_close(out, g['out'], tol=1e-4)
+    dq, dkv = dec(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert_close(dq, g['dq'], tol=1e-4)
+    assert_close(dkv, g['dkv'], tol=1e-4)
+    for k, (path, attr) in _DEC.items():
+        assert_close(getattr(_sub(dec, path), attr), g[k + '__1'], tol=1e-4, what=k)
+
+
 @pytest.mark.parametrize('norm_first', [True, False])
 def test_decoder_fused_equals_unfused(npm, norm_first):
     """The fused decoder composition (residuals and the dkey + dvalue / dq + dk + dv sums in GEMM epilogues and the

@@ -129,6 +129,32 @@ def test_decoder_fused_composition_on_simulator(npm, name):
     assert_close(dec._norm3._gamma, g['n3_gamma__1'], tol=1e-4)
 
 
+@pytest.mark.parametrize('name', ['decoder_dropout_prenorm', 'decoder_dropout_postnorm'])
+def test_decoder_with_dropout_reproduces_the_reference_run(npm, name):
+    """The reference's seeded decoder run with drop_rate = 0.1 (tests/golden/decoder_dropout_*.npz): same parameters, same three
+    masks, then output, (dq, dkv) and updated parameters -- through the fused composition (npm_layernorm_dropout_* three times
+    each way, no standalone mask pass)."""
+    g = load_golden(name)
+    np.random.seed(0)
+    dec = npm.layers.TransformerDecoder(num_heads=int(g['heads']), hidden_units=int(g['hidden']),
+                                        norm_first=bool(g['norm_first']), drop_rate=float(g['drop_rate']))
+    del npm._C._LIB.calls[:]
+    out = dec(rand(g['q'].shape), rand(g['kv'].shape))
+    assert dec._fused and npm._C._LIB.calls.count('npm_layernorm_dropout_fwd') == 3 and 'npm_mask_scale' not in npm._C._LIB.calls
+    for i, d in enumerate((dec._dropout1, dec._dropout2, dec._dropout3), start=1):
+        np.testing.assert_array_equal(np.asarray(d._mask), g[f'mask{i}'])
+    np.testing.assert_array_equal(np.asarray(dec._cross_attention._wk), g['ca_wk__0'])
+    assert_close(out, g['out'], tol=1e-4)
+    del npm._C._LIB.calls[:]
+    dq, dkv = dec(g['dy'], backprop=True, learning_rate=float(g['lr']))
+    assert npm._C._LIB.calls.count('npm_layernorm_dropout_bwd') == 3 and 'npm_mask_scale' not in npm._C._LIB.calls
+    assert_close(dq, g['dq'], tol=1e-4)
+    assert_close(dkv, g['dkv'], tol=1e-4)
+    assert_close(dec._dense2.w, g['d2_w__1'], tol=1e-4)
+    assert_close(dec._cross_attention._wv, g['ca_wv__1'], tol=1e-4)
+    assert_close(dec._norm3._gamma, g['n3_gamma__1'], tol=1e-4)
+
+
 def test_weights_rebound_between_forward_and_backward(npm):
     """The packed q/k/v projection must not assume the parameters are still adjacent in the backward:
     bench.py (and weight binders) rebind them after the first forward."""

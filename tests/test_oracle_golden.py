@@ -212,6 +212,25 @@ def test_decoder(name, verbatim):
         close_scaled(O.sgd_step(p[k], grad, float(g['lr'])), g[k + '__1'], tol)
 
 
+@pytest.mark.parametrize('name', ['decoder_dropout_prenorm', 'decoder_dropout_postnorm'])
+def test_decoder_with_dropout(name):
+    """drop_rate = 0.1 in the decoder (transformer.py:98,111-113): with the three masks the reference drew, the oracle reproduces
+    its output, (dq, dkv) and all 26 updated parameters (same-order flavour; tolerances as in test_decoder)."""
+    g = load_golden(name)
+    nf = bool(g['norm_first'])
+    p = {k[:-3]: v for k, v in g.items() if k.endswith('__0')}
+    drop = (g['mask1'], g['mask2'], g['mask3'], 1.0 - float(g['drop_rate']))
+    assert g['mask3'].shape == (g['q'].shape[0] * g['q'].shape[1], g['q'].shape[2]) and 0.8 < g['mask2'].mean() < 0.97
+    out, cache = O.decoder_fwd(p, g['q'], g['kv'], nf, verbatim=True, drop=drop)
+    close_scaled(out, g['out'], 1e-5)
+    (dq, dkv), grads = O.decoder_bwd(p, cache, g['dy'], nf, verbatim=True)
+    close_scaled(dq, g['dq'], 1e-5)
+    close_scaled(dkv, g['dkv'], 1e-5)
+    assert len(grads) == 26
+    for k, grad in grads.items():
+        close_scaled(O.sgd_step(p[k], grad, float(g['lr'])), g[k + '__1'], 1e-5)
+
+
 def test_losses():
     g = load_golden('losses')
     np.testing.assert_allclose(O.mse_fwd(g['y'], g['t']), g['mse'], rtol=1e-6)
