@@ -7,11 +7,12 @@
 # NPM_REFRESH_PART=pmc runs only the PMC traffic passes and the default bench line (after a change of the sources that does not
 # move any timing: profiles/pmc_traffic.json and the bench line name the build they were taken on).
 # NPM_REFRESH_PART=1 | 2 runs one half (a gpurun call is limited to 20 minutes): 1 = PMC traffic, bench, clocks, configs, GEMM shapes,
-# row kernels, the round-5 logs; 2 = attention, parity, exchange path, kernel traces, counters, timelines.
+# row kernels, the dropout line; 2 = attention, parity, exchange path, kernel traces, counters, timelines.
+# (Round 5's one-off logs -- exchange shadow, LayerNorm hint placement, row terms from the dctx GEMM -- are not re-taken: that code is unchanged.)
 set -o pipefail
 PART=${NPM_REFRESH_PART:-all}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
-R=${NPM_ROUND:-r05}
+R=${NPM_ROUND:-r06}
 OUT=$REPO/gpurun_out/profiles_new
 mkdir -p "$OUT"
 cd "$REPO"
@@ -35,13 +36,9 @@ echo "== config bench (f32)"; { timeout -k 10 300 python tools/config_bench.py -
   echo "-- C3 with the K loop of forward / grad_x by taps (NPM_TUNE 16=0: round 3) and by 16-channel chunks (16=1: default), alternating"; for k in 0 1 0 1; do echo "NPM_TUNE=16=$k"; NPM_TUNE=16=$k timeout -k 10 200 python tools/config_bench.py --only C3 --kernels; done; } > "$OUT/${R}_config_bench.log" 2>&1
 echo "== gemm shapes (f32)"; timeout -k 10 200 python tools/gemm_bench.py --tune 10=0 > "$OUT/${R}_gemm_shapes.log" 2>&1
 echo "== row kernels"; timeout -k 10 200 python tools/rowops_bench.py > "$OUT/${R}_rowops.log" 2>&1
-echo "== round 5: exchange shadow (the 8-GPU step bounded on one GPU), LayerNorm hint placement, row terms from the dctx GEMM"
-timeout -k 10 500 python tools/exchange_shadow.py > "$OUT/${R}_exchange_shadow.log" 2>&1
-{ echo "# LayerNorm: where the nontemporal hint sits (NPM_TUNE_LN_NT_SPLIT = backward mode + 4 * forward mode; mode 0 loads and stores, 1 loads only, 2 stores only)";
-  echo "# tools/ln_nt_split.py: backward + residual alone, 131072 x 1024, cold caches / right behind the kernel that wrote dz"; timeout -k 10 120 python tools/ln_nt_split.py;
-  echo "# tools/ln_instep.sh: inside the encoder step (bench.py hbm_kernels: (ms per call incl. the column sum, fraction of 8 TB/s)); 5 = shipped, 0 = rounds 2-4, 1 = backward only, 9 = forward stores only"; timeout -k 10 600 bash tools/ln_instep.sh 19=5 19=0 19=1 19=9; } > "$OUT/${R}_ln_nt_split.log" 2>&1
-{ echo "# bench.py --steps 20 --warmup 5 (headline step only), alternating: row terms from the epilogue of the dctx GEMM (NPM_ATTN_ROWDOT=1, shipped) against the pass inside npm_mha_core_bwd (0, rounds 3-4)";
-  for i in 1 2 3; do for r in 1 0; do echo "NPM_ATTN_ROWDOT=$r: $(NPM_ATTN_ROWDOT=$r timeout -k 10 200 python bench.py --steps 20 --warmup 5 --no-alt-math --no-configs --no-cpu-baseline 2>/dev/null | python3 tools/bench_brief.py)"; done; done; } > "$OUT/${R}_attn_rowdot_ab.log" 2>&1
+echo "== round 6: the encoder with drop_rate 0.1 (C5D: device-drawn masks applied inside the LayerNorm kernels) against the same harness without dropout (C5), alternating"
+{ echo "# tools/config_bench.py --only C5D / --only C5 --kernels, alternating in one session (both not BASELINE.json configs; C5 = bench.py's headline workload in this harness)";
+  for i in 1 2; do for c in C5 C5D; do timeout -k 10 200 python tools/config_bench.py --only $c --kernels --min-seconds 1.0; done; done; } > "$OUT/${R}_dropout_fused.log" 2>&1
 fi   # part 1
 if [ "$PART" != 1 ]; then
 echo "== fused attention core"; { echo "-- saved scores (the default from head size 64 up), then recomputing; medians of 15 back-to-back launches after 30 untimed";
@@ -55,7 +52,7 @@ echo "== fused attention core"; { echo "-- saved scores (the default from head s
   echo "-- stamps of the 4-wave kernels, scores recomputed"; timeout -k 10 100 python tools/attn_trace.py; echo "-- stamps, scores saved"; timeout -k 10 100 python tools/attn_trace.py --save-scores; } > "$OUT/${R}_attn_core.log" 2>&1
 echo "== phase stamps of the shipped backward (diagnostic instance)"; timeout -k 10 200 python tools/attn_trace.py --bwd16 2>&1 | sed -n "/mha_bwd16_kernel, thread 0/,\$p" > "$OUT/${R}_attn_bwd16_phases_trace.log"   # (profiles/r04_attn_bwd16_phases.log = this + two experiments appended by hand)
 echo "== attention: saved against recomputed scores per head size"; timeout -k 10 400 bash tools/attn_modes.sh > "$OUT/${R}_attn_modes.log" 2>&1
-echo "== parity report (f32)"; timeout -k 10 600 python -c "import sys; sys.path.insert(0, 'tools'); import parity_report; parity_report.main(modes=('f32',))" > "$OUT/${R}_parity_relative_error.log" 2>&1
+echo "== parity report (every math mode bench.py reports: f32, bf16x3, f16x2)"; timeout -k 10 900 python tools/parity_report.py > "$OUT/${R}_parity_relative_error.log" 2>&1
 echo "== exchange path on one GPU: bench.py without and with a one-rank RCCL communicator (NPM_FORCE_RCCL=1)"
 { echo "bench.py --steps 30 --warmup 5 --no-alt-math --no-configs --no-cpu-baseline, alternating; exchange = rank 0's HIP-event statistics per step";
   for i in 1 2 3; do for f in 0 1; do
