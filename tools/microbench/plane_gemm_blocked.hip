@@ -181,6 +181,104 @@ plane_gemm(const unsigned char *__restrict__ Ap, size_t plane_a, long rows_a, co
                                                       (i * 32 + (rr & 3) + 8 * (rr >> 2)) * N * 4, 0);
 }
 
+// ---- hybrid: A fp32 [M][K] staged as in the product kernel (LDS-DMA, K-major tile with the bank swizzle on the source address) and split
+// into three bf16 parts in REGISTERS after the LDS read; B from pre-split tile-blocked planes (a weight matrix: split once per call for
+// a few microseconds).  Half of the shipped bf16x3 kernel's split work, 20 KB per K step instead of 16 (fp32 both) or 24 (planes both).
+__device__ __forceinline__ float sub_f32(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4 &hi, u32x4 &mid, u32x4 &lo) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        const unsigned h = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{v[2 * t], v[2 * t + 1]}, bf16x2));
+        const float p0 = sub_f32(v[2 * t], __uint_as_float(h << 16)), p1 = sub_f32(v[2 * t + 1], __uint_as_float(h & 0xffff0000u));
+        const unsigned m0 = __float_as_uint(p0), m1 = __float_as_uint(p1);
+        const float q0 = sub_f32(p0, __uint_as_float(m0 & 0xffff0000u)), q1 = sub_f32(p1, __uint_as_float(m1 & 0xffff0000u));
+        hi[t] = h;
+        mid[t] = __builtin_amdgcn_perm(m1, m0, 0x07060302);
+        lo[t] = __builtin_amdgcn_perm(__float_as_uint(q1), __float_as_uint(q0), 0x07060302);
+    }
+}
+
+constexpr int HSTAGE = TM * GK * 2 + 3 * PLANE_TILE;      // in 2-byte units: A fp32 tile 8 KB + B planes 12 KB = 20 KB
+
+__global__ void __launch_bounds__(256, 2)
+hybrid_gemm(const float *__restrict__ A, const unsigned char *__restrict__ Bp, size_t plane_b, long rows_b, float *__restrict__ C, int M, int N, int K) {
+    __shared__ __attribute__((aligned(16))) unsigned short smem[2 * HSTAGE];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1, l32 = lane & 31, half = lane >> 5;
+    const int tiles_n = N / TN;
+    const int nwg = gridDim.x, xcd = blockIdx.x & 7, q = nwg >> 3, r = nwg & 7;
+    const int logical = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (blockIdx.x >> 3);
+    const int per_group = 8 * tiles_n, gid = logical / per_group, first = gid * 8;
+    const int rows_in = min(8, M / TM - first), in = logical - gid * per_group;
+    const int tm = first + in % rows_in, tn = in / rows_in;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int nkt = K / GK;
+    const auto rA = __builtin_amdgcn_make_buffer_rsrc((void *)(A + (size_t)m0 * K), 0, (int)((size_t)TM * K * 4), 0x00020000);
+    __amdgpu_buffer_rsrc_t rb[3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl)
+        rb[pl] = __builtin_amdgcn_make_buffer_rsrc((void *)(Bp + pl * plane_b + (size_t)n0 * 32), 0, (int)(plane_b - (size_t)n0 * 32), 0x00020000);
+    unsigned va[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {                                     // A pieces 2 w, 2 w + 1: 16 rows x 64 B each
+        const int row = 16 * (2 * wave + i) + (lane >> 2);
+        va[i] = (unsigned)(row * K * 4 + (((lane & 3) ^ ((row >> 2) & 3)) * 16));
+    }
+    const unsigned vb = (unsigned)(wave * 1024 + lane * 16);
+    const unsigned bstep = (unsigned)(rows_b * 32);
+    auto issue = [&](int kt, int stage) {
+        unsigned short *base = smem + stage * HSTAGE;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rA, (lds_void *)(base + (2 * wave + i) * 512), 16, va[i], kt * GK * 4, 0, 0);
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rb[pl], (lds_void *)(base + TM * GK * 2 + pl * PLANE_TILE + wave * 512), 16, vb, kt * bstep, 0, 0);
+    };
+    f32x16 acc[2][2] = {}, small[2][2] = {};
+    const int arow = wm * 64 + l32, brow = wn * 64 + l32;
+    const int fsw = (half ^ ((l32 >> 3) & 1)) * 8;
+    const int asw = (arow >> 2) & 3;                                  // same for arow + 32
+    issue(0, 0);
+    for (int kt = 0; kt < nkt; ++kt) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+        const unsigned short *st = smem + (kt & 1) * HSTAGE;
+        const float *sA = reinterpret_cast<const float *>(st);
+        u32x4 a[2][3], b[2][3];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const float4 x = *reinterpret_cast<const float4 *>(sA + (arow + 32 * i) * GK + ((2 * half) ^ asw) * 4);
+            const float4 y = *reinterpret_cast<const float4 *>(sA + (arow + 32 * i) * GK + ((2 * half + 1) ^ asw) * 4);
+            const float v[8] = {x.x, x.y, x.z, x.w, y.x, y.y, y.z, y.w};
+            split8(v, a[i][0], a[i][1], a[i][2]);
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                b[i][pl] = *reinterpret_cast<const u32x4 *>(st + TM * GK * 2 + pl * PLANE_TILE + (brow + 32 * i) * GK + fsw);
+        }
+#define TERM(PA, PB, ACC)                                                           \
+    _Pragma("unroll") for (int i = 0; i < 2; ++i)                                   \
+    _Pragma("unroll") for (int j = 0; j < 2; ++j) mfma(a[i][PA], b[j][PB], ACC[i][j]);
+        TERM(2, 0, small) TERM(0, 2, small) TERM(1, 1, small) TERM(1, 0, small) TERM(0, 1, small)
+        TERM(0, 0, acc)
+#undef TERM
+    }
+    float *cbase = C + (size_t)(m0 + wm * 64) * N + n0 + wn * 64;
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc((void *)cbase, 0, (int)(64 * (size_t)N * 4), 0x00020000);
+    const int vo = (4 * half * N + l32) * 4;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[i][j][rr] + small[i][j][rr]), rc, vo + j * 128,
+                                                      (i * 32 + (rr & 3) + 8 * (rr >> 2)) * N * 4, 0);
+}
+
 static long pad128(long x) { return (x + 127) / 128 * 128; }
 
 int main() {
@@ -211,6 +309,18 @@ int main() {
                 se += e * e; me += e; mx = std::fmax(mx, std::fabs(ref));
             }
         printf("check: rms err %.3e, mean err %+.3e, max|ref| %.3g (NSTAGE %d)\n", std::sqrt(se / (M * N)), me / (M * N), mx, NSTAGE);
+        hybrid_gemm<<<(M / TM) * (N / TN), 256>>>(da, pb, plb, pad128(N), dc, M, N, K);
+        CK(hipDeviceSynchronize());
+        CK(hipMemcpy(c.data(), dc, c.size() * 4, hipMemcpyDeviceToHost));
+        se = me = 0;
+        for (int i = 0; i < M; ++i)
+            for (int j = 0; j < N; ++j) {
+                double ref = 0;
+                for (int k = 0; k < K; ++k) ref += (double)a[(size_t)i * K + k] * b[(size_t)k * N + j];
+                const double e = c[(size_t)i * N + j] - ref;
+                se += e * e; me += e;
+            }
+        printf("check hybrid (A fp32 split in registers, B planes): rms err %.3e, mean err %+.3e\n", std::sqrt(se / (M * N)), me / (M * N));
         CK(hipFree(da)); CK(hipFree(db)); CK(hipFree(dc)); CK(hipFree(pa)); CK(hipFree(pb));
     }
     // ---- speed at the encoder's GEMM shapes ------------------------------------------------------------------
@@ -240,6 +350,17 @@ int main() {
         float ms = 0;
         CK(hipEventElapsedTime(&ms, e0, e1));
         ms /= reps;
+        hybrid_gemm<<<grid, 256>>>(a32, pb, plb, pad128(N), c, M, N, K);
+        CK(hipDeviceSynchronize());
+        CK(hipEventRecord(e0));
+        for (int i = 0; i < reps; ++i) hybrid_gemm<<<grid, 256>>>(a32, pb, plb, pad128(N), c, M, N, K);
+        CK(hipEventRecord(e1));
+        CK(hipDeviceSynchronize());
+        float hms = 0;
+        CK(hipEventElapsedTime(&hms, e0, e1));
+        hms /= reps;
+        printf("M=%d N=%d K=%d: HYBRID (A fp32 split in registers, B planes) %.3f ms = %.1f TFLOP/s fp32-equivalent (%.1f %% of 2516)\n", M, N, K, hms,
+               2.0 * M * N * K / hms * 1e-9, 100.0 * 12.0 * M * N * K / hms * 1e-9 / 2516.0);
         float sp[2] = {0, 0};
         for (int form = 0; form < 2; ++form) {           // the split passes over A: K-major source, and the same bytes read as [K][M]
             CK(hipEventRecord(e0));
