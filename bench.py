@@ -249,25 +249,10 @@ def main():
         enc(dy, backprop=True, optimizer_=sgd)
 
     for i in range(args.warmup):
-        # the LAST warm-up step runs the way the timed steps do -- under a (discarded) kernel timer, between two step-boundary
-        # events -- so that the first timed step touches nothing for the first time (on a fresh box the first use of a code path
-        # pages it in: one timed step of a first-process run once read 109 ms, profiles/r06_bench_hiccup.log)
-        rehearse = i == args.warmup - 1 and not args.no_kernel_timer
-        dummy = D.KernelTimer() if rehearse else None
-        if dummy is not None:
-            dummy.__enter__()
-            D.Event().record()
         if i > 0:
             enc(qkv)                                     # (step 0's forward ran above, before bind)
         enc(dy, backprop=True, optimizer_=sgd)
-        if dummy is not None:
-            D.Event().record()
-            dummy.__exit__(None, None, None)
-            dummy.summary()
     D.synchronize()
-    import gc
-    gc.collect()
-    gc.disable()                                         # no collector pause inside a timed region (re-enabled below)
     if comm.active:
         comm.barrier()
 
@@ -291,7 +276,6 @@ def main():
     elapsed = time.perf_counter() - t0
     if timer is not None:
         timer.__exit__(None, None, None)
-    gc.enable()
     step_order = [marks[i].elapsed_ms(marks[i + 1]) for i in range(args.steps)]
     step_ms = sorted(step_order)
     exchange_stats = comm.stats() if rccl else None
