@@ -158,6 +158,79 @@ def test_encoder_full_size_fused_equals_unfused(npm):
         assert_close(g1[k], g2[k], tol=2e-5, what=str(k[:2]))
 
 
+def test_encoder_full_size_with_dropout(npm):
+    """The headline shapes (d_model 1024, 8 heads, seq 512, U 4096; batch 64 here) with drop_rate 0.1 and masks drawn on the
+    device: the fused composition (both DropOuts applied inside the LayerNorm kernels, reference transformer.py:35-36,49-50 and
+    normalizations.py:21-30) against (1) the oracle on two samples of the batch, evaluated with the very masks the device drew,
+    and (2) the literal composition (DropOut layer -> norm -> ... -> standalone adds) under the same seed: same masks, outputs,
+    input gradient and parameter gradients equal to rounding."""
+    D = npm.device
+    from np_modeling_amd import parallel
+    rng = np.random.default_rng(6)
+    b = 64
+    x = rng.standard_normal([b, S, F], dtype=np.float32)
+    dy = rng.standard_normal([b, S, F], dtype=np.float32) * np.float32(0.01)
+    runs = {}
+    try:
+        for fused in (True, False):
+            npm.set_dropout_rng('device', seed=4242)
+            enc = npm.layers.TransformerEncoder(num_heads=H, hidden_units=U, norm_first=True, drop_rate=0.1)
+            enc(npm.as_device(np.zeros([1, 8, F], dtype=np.float32)))          # lazy init (consumes Philox offsets 0, 1)
+            prng = np.random.default_rng(60)
+            p = {}
+            for key, (obj, attr, scale) in dict(
+                    att_wq=(enc._self_attention, '_wq', 1 / np.sqrt(F)), att_wk=(enc._self_attention, '_wk', 1 / np.sqrt(F)),
+                    att_wv=(enc._self_attention, '_wv', 1 / np.sqrt(F)), att_wo=(enc._self_attention, '_wo', 1 / np.sqrt(F)),
+                    att_bq=(enc._self_attention, '_bq', 1.0), att_bk=(enc._self_attention, '_bk', 1.0),
+                    att_bv=(enc._self_attention, '_bv', 1.0), att_bo=(enc._self_attention, '_bo', 1.0),
+                    n1_gamma=(enc._norm1, '_gamma', 1.0), n1_beta=(enc._norm1, '_beta', 1.0),
+                    n2_gamma=(enc._norm2, '_gamma', 1.0), n2_beta=(enc._norm2, '_beta', 1.0),
+                    d1_w=(enc._dense1._linear, '_w', 1 / np.sqrt(F)), d1_b=(enc._dense1._linear, '_b', 1.0),
+                    d2_w=(enc._dense2, '_w', 1 / np.sqrt(U)), d2_b=(enc._dense2, '_b', 1.0)).items():
+                arr = getattr(obj, attr)
+                new = (np.clip(prng.standard_normal(arr.shape), -1, 1) * scale).astype(np.float32)
+                arr.set(new)
+                p[key] = new.astype(np.float64)
+            rec = GradRecorder()
+            if fused:
+                out = enc(D.from_host(x))
+                assert enc._fused
+                dx = enc(D.from_host(dy), backprop=True, optimizer_=rec)
+            else:
+                out = enc._forward_unfused(D.from_host(x))
+                with parallel.grad_scope(0) as scope:
+                    dx = enc._backward_unfused(D.from_host(dy), rec, scope)
+            masks = (np.asarray(enc._dropout1._mask) != 0, np.asarray(enc._dropout2._mask) != 0)
+            tags = {id(enc._self_attention): 'att', id(enc._norm1): 'n1', id(enc._norm2): 'n2', id(enc._dense1._linear): 'd1',
+                    id(enc._dense2): 'd2'}
+            runs[fused] = (out.numpy(), dx.numpy(), masks, {(tags[k[2]], k[1]): np.asarray(v) for k, v in rec.grads.items()}, p)
+    finally:
+        npm.set_dropout_rng('host')
+    out_f, dx_f, masks_f, grads_f, p = runs[True]
+    out_u, dx_u, masks_u, grads_u, _ = runs[False]
+    for a, c in zip(masks_f, masks_u):
+        np.testing.assert_array_equal(a, c)
+        assert abs(a.mean() - 0.9) < 1e-3
+    assert_close(out_f, out_u, tol=3e-6)
+    assert_close(dx_f, dx_u, tol=1e-5)
+    assert grads_f.keys() == grads_u.keys() and len(grads_f) == 16
+    bq_scale = max(np.abs(v).max() for k, v in grads_f.items() if k[1] == '_bq')
+    for k in grads_f:
+        if k[1] == '_bk':          # exactly zero in real arithmetic: rounding noise (see the additivity test above)
+            assert np.abs(grads_f[k]).max() < 1e-4 * bq_scale
+            continue
+        assert_close(grads_f[k], grads_u[k], tol=2e-5, what=str(k))
+    # the oracle on two samples, with the device's masks
+    sl = slice(30, 32)
+    m1, m2 = masks_f[0][sl], masks_f[1].reshape(b, S, F)[sl].reshape(2 * S, F)
+    want, cache = O.encoder_fwd(p, x[sl].astype(np.float64), True, drop=(m1, m2, 0.9))
+    want_dx, _ = O.encoder_bwd(p, cache, dy[sl].astype(np.float64), True)
+    assert_close(out_f[sl], want, tol=1e-5)
+    near_zero = (np.abs(cache['d1_pre']) < 5e-6).any(axis=1).reshape(2, S)
+    assert near_zero.mean() < 0.05
+    assert_close(dx_f[sl][~near_zero], want_dx[~near_zero], tol=1e-5)
+
+
 def test_dense_c2_checksum(npm, exact_modes):
     """BASELINE configs[1]: Dense(4096 -> 4096) + ReLU, batch 4096: (x w + b) 1 == x (w 1) + sum(b) on the
     pre-activation, ReLU bit-exact from it, and the backward identities dw 1 = x^T (g 1), 1^T dx = (1^T g) w^T."""
